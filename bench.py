@@ -1,0 +1,154 @@
+#!/usr/bin/env python3
+"""Headline benchmark: particle-steps/s of the SPH frame update on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W        (N=1 default; N>1 via torch.distributed.run)
+
+One "step" = one reference frame, SphFluidSimulation.cs::Update (:96-102): grid build + density
+pass + 5 force/integrate sub-steps, on the synthetic dam-break of BASELINE.json
+(16 777 216 particles, R = 185, scene parameters, dt_frame = 0.7667 h).  Inputs are resident in
+HBM before the timed region.  Prints ONE JSON line (rank 0).
+
+Extra objects on that line:
+  roofline      dominant kernel (VelPos replacement): algorithmic bytes per launch
+                (52 B/particle) / its mean launch duration from HIP events recorded
+                on the engine's stream inside the timed region, against the 8 TB/s HBM peak.
+                The sweeps are FP32-VALU bound, so valu_frac is reported next to it.
+  cpu_baseline  oracle/ (CPU restatement of the reference, "port") timed on this host for ONE frame
+                of the same workload, all OpenMP threads; also used to check the GPU result.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+VALU_PEAK_TFLOPS = 157.3       # fp32 vector peak
+BYTES_PER_SUBSTEP = 52         # (12 pos + 12 vel + 4 rho) R + (12 + 12) W
+BYTES_PER_STEP = 32 + 52 * 5   # 292 B per particle-step at S = 5
+FLOPS_DENSITY, FLOPS_FORCE = 16, 55  # per candidate, SURVEY.md 8d
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--particles", type=int, default=16777216)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(n, R, fill, pos0, vel0, dt_frame):
+    """Oracle timed on the host cores for one frame of the same workload (checker + baseline)."""
+    from oracle import sph_oracle as O
+    O.build()
+    threads = O.max_threads()
+    p = O.derive(n, R, fill, viscosity=0.01, rest_density=1.5, gas_constant=150.0, stiffness=5000.0,
+                 damping=10.0, num_threads=threads)
+    sim = O.OracleSimulation(p)
+    sim.upload(pos0, vel0)
+    t0 = time.perf_counter()
+    sim.Update(dt_frame)
+    dt = time.perf_counter() - t0
+    out = sim.download()
+    sim.close()
+    return dict(value=n / dt, unit="particle-steps/s", cores=threads, kind="port",
+                sample=f"1 frame (grid + density + 5 sub-steps) of the same {n}-particle dam-break, "
+                       f"{dt:.2f} s wall, OpenMP {threads} threads, gcc -O2 -ffp-contract=off"), out
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus != world:
+        if world == 1 and a.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+    import torch
+    import torch.distributed as dist
+
+    from sphfluidsimulation_amd import presets
+
+    n, fill = presets.next_power_of_two(a.particles), 0.8
+    R = presets.scene_bucket_resolution(n)
+    dt_frame = presets.bench_dt_frame(R)
+    workload = f"dam-break Preset1 lattice, {n} particles, R={R}, fill 0.8, scene parameters, dt_frame=0.7667h, seed {a.seed}"
+
+    if world > 1:
+        from sphfluidsimulation_amd import distributed as D
+        result = D.bench_main(a, n, R, fill, dt_frame, rank, world, local_rank)
+        if rank == 0:
+            result["config"]["workload"] = workload
+            print(json.dumps(result), flush=True)
+        return
+
+    from sphfluidsimulation_amd.simulation import SphFluidSimulation
+    torch.cuda.set_device(0)
+    pos0, vel0 = presets.dam_break(n, fill, a.seed)
+    sim = SphFluidSimulation(particleNumber=n, bucketResolution=R, damFillRate=fill, viscosity=0.01,
+                             restDensity=1.5, gasConstant=150.0, stiffnessCoefficient=5000.0,
+                             dampingCoefficient=10.0, device_id=0, profile=True).Start(pos0, vel0)
+
+    # GPU result of frame 1, checked against the CPU baseline run below
+    warm = max(a.warmup, 1)
+    sim.Update(dt_frame)
+    frame1 = sim.download()
+    sim.step_n(dt_frame, warm - 1)
+    sim.synchronize()
+    sim.reset_stats()
+
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    sim.step_n(dt_frame, a.steps)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+
+    st = sim.stats()
+    ms_per_step = elapsed * 1e3 / a.steps
+    value = n * a.steps / elapsed
+    pbar = st["candidates_density"] / n
+    vel_ms = st["ms_velpos"] / max(st["launches_velpos"], 1)
+    achieved = BYTES_PER_SUBSTEP * n / (vel_ms * 1e-3) / 1e9 if vel_ms > 0 else 0.0
+    valu_tflops = value * pbar * (FLOPS_DENSITY + FLOPS_FORCE * 5) / 1e12
+    out = {
+        "metric": "particle-steps/s", "value": value, "unit": "particle-steps/s", "n_gpus": 1,
+        "steps": a.steps, "warmup": warm, "ms_per_step": ms_per_step, "higher_is_better": True,
+        "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": workload, "particles": n, "bucket_resolution": R, "substeps": 5,
+                   "mode": "exact_order"},
+        "roofline": {
+            "bound": "hbm", "kernel": "k_velpos_exact", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            "kernel_ms": vel_ms, "launches": st["launches_velpos"],
+            "step_hbm_frac": value * BYTES_PER_STEP / (HBM_PEAK_GBS * 1e9),
+            "valu_frac": valu_tflops / VALU_PEAK_TFLOPS,
+            "candidates_per_particle": pbar,
+        },
+        "passes_ms": {"grid": st["ms_grid"] / max(st["launches_grid"], 1),
+                      "density": st["ms_density"] / max(st["launches_density"], 1),
+                      "velpos": vel_ms},
+        "particle_substeps_per_s": value * 5,
+        "max_cell_occupancy": st["max_cell_occupancy"], "nan_resets": st["nan_resets"],
+    }
+    if not a.no_cpu_baseline:
+        base, (po, vo, ro) = cpu_baseline(n, R, fill, pos0, vel0, dt_frame)
+        out["cpu_baseline"] = base
+        out["parity_frame1_max_abs_diff"] = {
+            "pos": float(np.abs(frame1[0] - po).max()), "vel": float(np.abs(frame1[1] - vo).max()),
+            "rho": float(np.abs(frame1[2] - ro).max())}
+    sim.OnDestroy()
+    print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,157 @@
+/*
+ * sph_hip.h -- C ABI of libsph_hip.so, the MI355X-native (gfx950) replacement for ONE path of
+ * leandro-barcelos/SPHFluidSimulation: the per-frame particle update that
+ * Assets/Scripts/SphFluidSimulation.cs::Update (:96-102) dispatches against
+ * Assets/Resources/{Clear,Bucket,Density,VelPos}.compute.
+ *
+ * The reference has NO plugin/FFI boundary: the C# MonoBehaviour talks to the GPU through Unity's
+ * ComputeShader API (Resources.Load :128-133, SetInt/SetFloat/SetVector/SetTexture/SetBuffer +
+ * Dispatch :206-220, :229-240, :245-265).  This header is what a C# P/Invoke binding
+ * ([DllImport("sph_hip")], CallingConvention.Cdecl -- see INTEGRATION.md) binds instead.  Each
+ * entry point names the reference interface it replaces.
+ *
+ * Conventions
+ *   - every call returns SPH_OK (0) or a negative SPH_E_* code; text via sph_last_error();
+ *     nothing throws or aborts across the ABI.  NaN accelerations, overflowing cells and
+ *     out-of-grid particles are COUNTED (SphStats), not errors -- reference semantics are kept.
+ *   - host arrays are the reference's texture memory: float4 per particle, row-major
+ *     res x res, particle id = y*res + x (Bucket.compute:24, VelPos.compute:55).
+ *     pos.w == 1 and vel.w == sub-step counter / 0.003 NaN marker (VelPos.compute:146,150-154).
+ *   - the engine owns all device memory (cell-sorted SoA, ping-pong); no host pointer is kept
+ *     after a call returns.
+ *   - a context is not thread-safe (the reference is driven from Unity's main thread only).
+ *     sph_step, sph_step_n, sph_bucket_generation, ... enqueue on the context's HIP stream and return
+ *     without a host sync; sph_download, sph_get_stats and sph_synchronize synchronise.
+ *   - there is NO CPU fallback: without a gfx950 device sph_create fails with SPH_E_HIP.
+ */
+#ifndef SPH_HIP_H
+#define SPH_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SPH_ABI_VERSION 1
+
+#define SPH_OK 0
+#define SPH_E_INVALID_ARG (-1)
+#define SPH_E_BAD_STATE (-2)
+#define SPH_E_OOM (-3)
+#define SPH_E_HIP (-4)
+#define SPH_E_UNSUPPORTED (-5)
+#define SPH_E_COMM (-6)
+
+/*
+ * The reference has no SimulationParameters type; this blittable struct (4-byte members only,
+ * LayoutKind.Sequential on the C# side) carries the inspector fields
+ * SphFluidSimulation.cs:35-45 plus the constants the reference hard-codes.
+ * Derived uniforms (h, h^2, h^6, h^9, m, res) are computed inside with the reference's own
+ * recipe (SphFluidSimulation.cs:84-85,159,176,236-237,255) and are never passed in.
+ */
+typedef struct SphParams {
+    uint32_t struct_size;       /* = sizeof(SphParams); guards against ABI drift                  */
+    uint32_t num_particles;     /* particleNumber :36 (raw; NextPowerOfTwo + (int)sqrt applied :84-85) */
+    uint32_t bucket_resolution; /* bucketResolution :37, 2..256                                     */
+    float dam_fill_rate;        /* damFillRate :38 (only enters through m = fill / N, :176)         */
+    float viscosity;            /* viscosity :41            -> _Viscosity                           */
+    float rest_density;         /* restDensity :42          -> _RestDensity                         */
+    float gas_constant;         /* gasConstant :43          -> _GasConst                            */
+    float stiffness_coeff;      /* stiffnessCoefficient :44 -> _StiffnessCoeff                      */
+    float damping_coeff;        /* dampingCoefficient :45   -> _DampingCoeff                        */
+    uint32_t max_per_voxel;     /* MaxParticlesPerVoxel :9 ; must be 32                             */
+    uint32_t substeps;          /* 5  (:101)                                                        */
+    float dt_divisor;           /* 25 (:102)                                                        */
+    float gravity[3];           /* (0,-9.8,0) VelPos.compute:7                                      */
+    uint32_t precision;         /* 0 = fp32 state (only value supported in this ABI version)        */
+    uint32_t exact_order;       /* 1 = accumulate neighbours in the reference's x,y,z / slot order  */
+    int32_t device_id;          /* HIP device ordinal                                               */
+    uint32_t flags;             /* SPH_FLAG_*                                                       */
+} SphParams;
+
+#define SPH_FLAG_PROFILE 1u     /* record HIP events around every pass (SphStats.ms_*)            */
+
+/* Values of the uniforms the reference pushes through ShaderIDs.cs:5-32. */
+typedef struct SphDerived {
+    uint32_t num_particles;       /* _NumParticles      (sentinel + mass divisor)   */
+    uint32_t particle_resolution; /* _ParticleResolution (res)                       */
+    uint32_t particle_count;      /* res*res = number of live particles              */
+    uint32_t bucket_resolution;   /* _BucketResolution                               */
+    float particle_mass;          /* _ParticleMass                                   */
+    float effective_radius;       /* _EffectiveRadius                                */
+    float effective_radius2;      /* _EffectiveRadius2                               */
+    float effective_radius6;      /* _EffectiveRadius6                               */
+    float effective_radius9;      /* _EffectiveRadius9                               */
+} SphDerived;
+
+typedef struct SphStats {
+    uint64_t frames;             /* sph_step frames (or BucketGeneration calls) since create     */
+    uint64_t substeps;           /* UpdateVelocityAndPosition passes since create                */
+    /* GPU time per pass, accumulated since the last sph_reset_stats (0 unless SPH_FLAG_PROFILE) */
+    double ms_grid;              /* cell keys + counting sort + reorder (replaces Bucket.compute) */
+    double ms_density;           /* Density.compute::CSMain replacement                          */
+    double ms_velpos;            /* VelPos.compute::CSMain replacement, all sub-steps            */
+    uint64_t launches_grid;      /* number of timed grid builds                                  */
+    uint64_t launches_density;
+    uint64_t launches_velpos;
+    /* state of the LAST grid build */
+    uint32_t max_cell_occupancy; /* before the 32-cap                                            */
+    uint32_t overflowed_cells;   /* cells holding more than max_per_voxel particles              */
+    uint32_t dropped_particles;  /* linear cell index outside the bucket         */
+    uint32_t reserved0;
+    uint64_t nan_resets;         /* NaN-guard hits (VelPos.compute:143-147) since create         */
+    uint64_t candidates_density; /* listed candidates visited by the last density pass (P-bar*N) */
+} SphStats;
+
+typedef struct SphContext SphContext;
+
+int sph_version(void);
+
+/* Inspector defaults, SphFluidSimulation.cs:35-45 (+ the hard-coded constants). */
+int sph_params_default(SphParams *out);
+
+/* Replaces Start(): InitShaders/CreateParticleTextures/InitializeBucketBuffer
+ * (SphFluidSimulation.cs:82-94,126-155,192-197).  Particle initialisation is the caller's
+ * (sph_upload), the reference does it with InitParticles.compute. */
+int sph_create(const SphParams *params, SphContext **out);
+
+/* Replaces OnDestroy() (SphFluidSimulation.cs:110-120). */
+int sph_destroy(SphContext *ctx);
+
+/* Writes _particlePositionTextures[Read] / _particleVelocityTextures[Read]
+ * (what InitParticles.compute + ClearFloat4 write at SphFluidSimulation.cs:182-189).
+ * pos4/vel4: res*res float4, id order.  vel4 may be NULL (= all zero, :189). */
+int sph_upload(SphContext *ctx, const float *pos4, const float *vel4);
+
+/* Reads back the Read textures (+ _particleDensityTexture).  Any pointer may be NULL. */
+int sph_download(SphContext *ctx, float *pos4, float *vel4, float *rho);
+
+/* One Update() (SphFluidSimulation.cs:96-102) with Time.deltaTime = delta_time:
+ * BucketGeneration, DensityCalculation, substeps x UpdateVelocityAndPosition(delta_time/25). */
+int sph_step(SphContext *ctx, float delta_time);
+int sph_step_n(SphContext *ctx, float delta_time, int frames);
+
+/* The three driver methods, for callers that keep the reference's dispatch granularity. */
+int sph_bucket_generation(SphContext *ctx);                      /* :203-221 (ClearBucket + CSMain) */
+int sph_density_calculation(SphContext *ctx);                    /* :223-241 (ClearFloat + CSMain)  */
+int sph_update_velocity_and_position(SphContext *ctx, float dt); /* :243-269 (CSMain + 2x Swap)     */
+
+/* Mid-run change of the inspector scalars (viscosity .. damping_coeff); sizes are fixed. */
+int sph_set_params(SphContext *ctx, const SphParams *params);
+int sph_get_derived(SphContext *ctx, SphDerived *out);
+int sph_get_stats(SphContext *ctx, SphStats *out);
+int sph_reset_stats(SphContext *ctx);
+int sph_synchronize(SphContext *ctx);
+
+/* Run on a caller-owned hipStream_t (e.g. torch's current stream) instead of the context's own. */
+int sph_set_stream(SphContext *ctx, void *hip_stream);
+
+/* Never NULL; ctx may be NULL for errors raised before a context exists. */
+const char *sph_last_error(SphContext *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPH_HIP_H */

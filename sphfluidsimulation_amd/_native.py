@@ -1,0 +1,143 @@
+"""ctypes binding of include/sph_hip.h (libsph_hip.so).  Fails loudly when the HIP library is
+missing or a call fails -- there is no CPU fallback behind this module."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libsph_hip.so")
+
+SPH_OK = 0
+SPH_E_INVALID_ARG = -1
+SPH_E_BAD_STATE = -2
+SPH_E_OOM = -3
+SPH_E_HIP = -4
+SPH_E_UNSUPPORTED = -5
+SPH_E_COMM = -6
+SPH_FLAG_PROFILE = 1
+
+_ERR_NAMES = {
+    SPH_E_INVALID_ARG: "SPH_E_INVALID_ARG", SPH_E_BAD_STATE: "SPH_E_BAD_STATE", SPH_E_OOM: "SPH_E_OOM",
+    SPH_E_HIP: "SPH_E_HIP", SPH_E_UNSUPPORTED: "SPH_E_UNSUPPORTED", SPH_E_COMM: "SPH_E_COMM",
+}
+
+
+class SphError(RuntimeError):
+    def __init__(self, code: int, message: str):
+        super().__init__(f"{_ERR_NAMES.get(code, code)}: {message}")
+        self.code = code
+
+
+class SphParams(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32),
+        ("num_particles", C.c_uint32),
+        ("bucket_resolution", C.c_uint32),
+        ("dam_fill_rate", C.c_float),
+        ("viscosity", C.c_float),
+        ("rest_density", C.c_float),
+        ("gas_constant", C.c_float),
+        ("stiffness_coeff", C.c_float),
+        ("damping_coeff", C.c_float),
+        ("max_per_voxel", C.c_uint32),
+        ("substeps", C.c_uint32),
+        ("dt_divisor", C.c_float),
+        ("gravity", C.c_float * 3),
+        ("precision", C.c_uint32),
+        ("exact_order", C.c_uint32),
+        ("device_id", C.c_int32),
+        ("flags", C.c_uint32),
+    ]
+
+
+class SphDerived(C.Structure):
+    _fields_ = [
+        ("num_particles", C.c_uint32),
+        ("particle_resolution", C.c_uint32),
+        ("particle_count", C.c_uint32),
+        ("bucket_resolution", C.c_uint32),
+        ("particle_mass", C.c_float),
+        ("effective_radius", C.c_float),
+        ("effective_radius2", C.c_float),
+        ("effective_radius6", C.c_float),
+        ("effective_radius9", C.c_float),
+    ]
+
+
+class SphStats(C.Structure):
+    _fields_ = [
+        ("frames", C.c_uint64),
+        ("substeps", C.c_uint64),
+        ("ms_grid", C.c_double),
+        ("ms_density", C.c_double),
+        ("ms_velpos", C.c_double),
+        ("launches_grid", C.c_uint64),
+        ("launches_density", C.c_uint64),
+        ("launches_velpos", C.c_uint64),
+        ("max_cell_occupancy", C.c_uint32),
+        ("overflowed_cells", C.c_uint32),
+        ("dropped_particles", C.c_uint32),
+        ("reserved0", C.c_uint32),
+        ("nan_resets", C.c_uint64),
+        ("candidates_density", C.c_uint64),
+    ]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+# every symbol include/sph_hip.h declares: name -> (restype, argtypes)
+_FP = C.POINTER(C.c_float)
+_CTX = C.c_void_p
+SYMBOLS = {
+    "sph_version": (C.c_int, []),
+    "sph_params_default": (C.c_int, [C.POINTER(SphParams)]),
+    "sph_create": (C.c_int, [C.POINTER(SphParams), C.POINTER(_CTX)]),
+    "sph_destroy": (C.c_int, [_CTX]),
+    "sph_upload": (C.c_int, [_CTX, _FP, _FP]),
+    "sph_download": (C.c_int, [_CTX, _FP, _FP, _FP]),
+    "sph_step": (C.c_int, [_CTX, C.c_float]),
+    "sph_step_n": (C.c_int, [_CTX, C.c_float, C.c_int]),
+    "sph_bucket_generation": (C.c_int, [_CTX]),
+    "sph_density_calculation": (C.c_int, [_CTX]),
+    "sph_update_velocity_and_position": (C.c_int, [_CTX, C.c_float]),
+    "sph_set_params": (C.c_int, [_CTX, C.POINTER(SphParams)]),
+    "sph_get_derived": (C.c_int, [_CTX, C.POINTER(SphDerived)]),
+    "sph_get_stats": (C.c_int, [_CTX, C.POINTER(SphStats)]),
+    "sph_reset_stats": (C.c_int, [_CTX]),
+    "sph_synchronize": (C.c_int, [_CTX]),
+    "sph_set_stream": (C.c_int, [_CTX, C.c_void_p]),
+    "sph_last_error": (C.c_char_p, [_CTX]),
+}
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """Load libsph_hip.so (built by sphfluidsimulation_amd.build / __graft_entry__.build())."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: build it with `python -m sphfluidsimulation_amd.build` "
+                "(hipcc, gfx950). The engine has no CPU fallback.")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(L, name)  # AttributeError if the library does not export it
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc: int, ctx=None):
+    if rc != SPH_OK:
+        msg = lib().sph_last_error(ctx)
+        raise SphError(rc, msg.decode() if msg else "")
+
+
+def default_params() -> SphParams:
+    p = SphParams()
+    check(lib().sph_params_default(C.byref(p)))
+    return p

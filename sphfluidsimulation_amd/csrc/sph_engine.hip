@@ -1,0 +1,532 @@
+// Host side of libsph_hip.so: context, device memory, the frame schedule of
+// SphFluidSimulation.cs::Update (:96-102) and the C ABI declared in include/sph_hip.h.
+#include "../../include/sph_hip.h"
+#include "sph_internal.hpp"
+
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+using namespace sph;
+
+static thread_local std::string g_last_error = "";
+
+struct PassEvents {
+    hipEvent_t a, b;
+    int kind;  // 0 grid, 1 density, 2 velpos
+};
+
+struct SphContext {
+    SphParams params{};
+    SphDerived derived{};
+    Dev dev{};
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::vector<void *> allocs;
+    // staging in the reference's texture layout
+    float4 *pos4_dev = nullptr, *vel4_dev = nullptr;
+    float *rho_id_dev = nullptr, *pw0 = nullptr;
+    bool uploaded = false, grid_valid = false;
+    int substeps_since_upload = 0;
+    float dt_last = 0.0f;
+    uint64_t frames = 0, substeps = 0;
+    // profiling
+    bool profile = false;
+    std::vector<PassEvents> pending;
+    std::vector<hipEvent_t> free_events;
+    double ms[3] = {0, 0, 0};
+    uint64_t launches[3] = {0, 0, 0};
+    std::string last_error;
+};
+
+static int fail(SphContext *ctx, int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->last_error = buf;
+    g_last_error = buf;
+    return code;
+}
+
+#define HIP_TRY(ctx, expr)                                                                      \
+    do {                                                                                        \
+        hipError_t _e = (expr);                                                                 \
+        if (_e != hipSuccess)                                                                   \
+            return fail(ctx, _e == hipErrorOutOfMemory ? SPH_E_OOM : SPH_E_HIP, "%s: %s", #expr, \
+                        hipGetErrorString(_e));                                                 \
+    } while (0)
+
+// ---- derived parameters: SphFluidSimulation.cs:84-85,159,176,236-237,255 -------
+
+static uint32_t next_power_of_two(uint32_t v)
+{
+    uint32_t p = 1;
+    while (p < v && p < 0x80000000u) p <<= 1;
+    return p;
+}
+
+static void derive(const SphParams &p, SphDerived *d)
+{
+    const uint32_t N = next_power_of_two(p.num_particles);               // :84
+    const uint32_t res = (uint32_t)(int32_t)(float)sqrt((double)(float)N); // :85 (int)Mathf.Sqrt
+    d->num_particles = N;
+    d->particle_resolution = res;
+    d->particle_count = res * res;
+    d->bucket_resolution = p.bucket_resolution;
+    d->effective_radius = 1.0f / (float)((int32_t)p.bucket_resolution - 1); // :159
+    d->particle_mass = p.dam_fill_rate / (float)(int32_t)N;              // :176
+    d->effective_radius2 = d->effective_radius * d->effective_radius;    // :236
+    d->effective_radius9 = (float)pow((double)d->effective_radius, 9.0); // :237 Mathf.Pow
+    d->effective_radius6 = (float)pow((double)d->effective_radius, 6.0); // :255
+}
+
+static void refresh_scalars(SphContext *c)
+{
+    const SphParams &p = c->params;
+    const SphDerived &dv = c->derived;
+    Dev &d = c->dev;
+    const float PI = 3.14159265358979323846264338327950288f;  // Density.compute:5, VelPos.compute:6
+    d.count = dv.particle_count;
+    d.sentinel_n = dv.num_particles;
+    d.R = dv.bucket_resolution;
+    d.num_cells = d.R * d.R * d.R;
+    d.Rm1 = (float)(d.R - 1u);
+    d.Rf = (float)d.R;
+    d.mass = dv.particle_mass;
+    d.h = dv.effective_radius;
+    d.h2 = dv.effective_radius2;
+    d.h9 = dv.effective_radius9;
+    d.c_poly6 = 315.0f / (64.0f * PI);                        // Density.compute:23
+    d.c_over_h6 = (45.0f / PI) / dv.effective_radius6;        // VelPos.compute:34,37,41,43
+    d.viscosity = p.viscosity;
+    d.gas_const = p.gas_constant;
+    d.rest_density = p.rest_density;
+    d.stiffness = p.stiffness_coeff;
+    d.damping = p.damping_coeff;
+    d.gx = p.gravity[0];
+    d.gy = p.gravity[1];
+    d.gz = p.gravity[2];
+}
+
+static int validate(SphContext *ctx, const SphParams *p)
+{
+    if (!p) return fail(ctx, SPH_E_INVALID_ARG, "params is NULL");
+    if (p->struct_size != sizeof(SphParams))
+        return fail(ctx, SPH_E_INVALID_ARG, "SphParams.struct_size %u != %zu (ABI mismatch)",
+                    p->struct_size, sizeof(SphParams));
+    if (p->num_particles == 0 || p->num_particles > (1u << 28))
+        return fail(ctx, SPH_E_INVALID_ARG, "num_particles %u out of range [1, 2^28]", p->num_particles);
+    if (p->bucket_resolution < 2 || p->bucket_resolution > 256)
+        return fail(ctx, SPH_E_INVALID_ARG, "bucket_resolution %u out of range [2, 256]", p->bucket_resolution);
+    if (p->max_per_voxel != kMaxPerVoxel)
+        return fail(ctx, SPH_E_UNSUPPORTED, "max_per_voxel must be 32 (MaxParticlesPerVoxel)");
+    if (p->substeps == 0 || p->substeps > 1000) return fail(ctx, SPH_E_INVALID_ARG, "substeps out of range");
+    if (!(p->dt_divisor > 0.0f)) return fail(ctx, SPH_E_INVALID_ARG, "dt_divisor must be > 0");
+    if (p->precision != 0) return fail(ctx, SPH_E_UNSUPPORTED, "precision %u not supported (fp32 only)", p->precision);
+    if (p->exact_order != 1) return fail(ctx, SPH_E_UNSUPPORTED, "exact_order=0 (fast mode) is not built in this version");
+    return SPH_OK;
+}
+
+template <typename T>
+static int dalloc(SphContext *c, T **out, size_t n)
+{
+    void *p = nullptr;
+    HIP_TRY(c, hipMalloc(&p, n * sizeof(T)));
+    c->allocs.push_back(p);
+    *out = (T *)p;
+    return SPH_OK;
+}
+
+static int alloc_soa(SphContext *c, Soa *s, size_t n)
+{
+    int rc;
+    float **f[] = {&s->x, &s->y, &s->z, &s->vx, &s->vy, &s->vz, &s->vw};
+    for (auto pp : f)
+        if ((rc = dalloc(c, pp, n)) != SPH_OK) return rc;
+    return SPH_OK;
+}
+
+// ---- profiling events ---------------------------------------------------------------------------
+
+static hipEvent_t get_event(SphContext *c)
+{
+    if (!c->free_events.empty()) {
+        hipEvent_t e = c->free_events.back();
+        c->free_events.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+static void fold_events(SphContext *c)
+{
+    for (auto &pe : c->pending) {
+        float ms = 0.0f;
+        (void)hipEventSynchronize(pe.b);
+        if (hipEventElapsedTime(&ms, pe.a, pe.b) == hipSuccess) {
+            c->ms[pe.kind] += ms;
+            c->launches[pe.kind]++;
+        }
+        c->free_events.push_back(pe.a);
+        c->free_events.push_back(pe.b);
+    }
+    c->pending.clear();
+}
+
+struct PassTimer {
+    SphContext *c;
+    PassEvents pe{};
+    bool on;
+    PassTimer(SphContext *ctx, int kind) : c(ctx), on(ctx->profile)
+    {
+        if (!on) return;
+        pe.kind = kind;
+        pe.a = get_event(c);
+        pe.b = get_event(c);
+        (void)hipEventRecord(pe.a, c->stream);
+    }
+    ~PassTimer()
+    {
+        if (!on) return;
+        (void)hipEventRecord(pe.b, c->stream);
+        c->pending.push_back(pe);
+        if (c->pending.size() >= 4096) fold_events(c);
+    }
+};
+
+// ---- the three driver passes ---------------------------------------------------------------------
+
+static int do_bucket_generation(SphContext *c)
+{
+    if (!c->uploaded) return fail(c, SPH_E_BAD_STATE, "BucketGeneration before sph_upload");
+    {
+        PassTimer t(c, 0);
+        launch_grid_build(c->dev, c->stream);
+    }
+    HIP_TRY(c, hipGetLastError());
+    std::swap(c->dev.cur, c->dev.nxt);
+    std::swap(c->dev.id, c->dev.id_nxt);
+    std::swap(c->dev.rho, c->dev.rho_nxt);
+    c->grid_valid = true;
+    c->frames++;
+    return SPH_OK;
+}
+
+static int do_density(SphContext *c)
+{
+    if (!c->grid_valid) return fail(c, SPH_E_BAD_STATE, "DensityCalculation before BucketGeneration");
+    {
+        PassTimer t(c, 1);
+        launch_density(c->dev, c->stream);
+    }
+    HIP_TRY(c, hipGetLastError());
+    return SPH_OK;
+}
+
+static int do_velpos(SphContext *c, float dt)
+{
+    if (!c->grid_valid) return fail(c, SPH_E_BAD_STATE, "UpdateVelocityAndPosition before BucketGeneration");
+    c->dev.dt = dt;
+    {
+        PassTimer t(c, 2);
+        launch_velpos(c->dev, c->stream);
+    }
+    HIP_TRY(c, hipGetLastError());
+    std::swap(c->dev.cur, c->dev.nxt);  // Swap(), SphFluidSimulation.cs:267-268
+    c->substeps++;
+    c->substeps_since_upload++;
+    c->dt_last = dt;
+    return SPH_OK;
+}
+
+// ---- C ABI -----------------------------------------------------------------------------------------
+
+extern "C" {
+
+int sph_version(void) { return SPH_ABI_VERSION; }
+
+int sph_params_default(SphParams *p)
+{
+    if (!p) return fail(nullptr, SPH_E_INVALID_ARG, "out is NULL");
+    memset(p, 0, sizeof *p);
+    p->struct_size = sizeof(SphParams);
+    p->num_particles = 1024;      // SphFluidSimulation.cs:36
+    p->bucket_resolution = 256;   // :37
+    p->dam_fill_rate = 0.5f;      // :38
+    p->viscosity = 0.01f;         // :41
+    p->rest_density = 1.5f;       // :42
+    p->gas_constant = 150.0f;     // :43
+    p->stiffness_coeff = 5000.0f; // :44
+    p->damping_coeff = 10.0f;     // :45
+    p->max_per_voxel = 32;        // :9
+    p->substeps = 5;              // :101
+    p->dt_divisor = 25.0f;        // :102
+    p->gravity[0] = 0.0f;         // VelPos.compute:7
+    p->gravity[1] = -9.8f;
+    p->gravity[2] = 0.0f;
+    p->precision = 0;
+    p->exact_order = 1;
+    p->device_id = 0;
+    p->flags = 0;
+    return SPH_OK;
+}
+
+int sph_create(const SphParams *params, SphContext **out)
+{
+    if (!out) return fail(nullptr, SPH_E_INVALID_ARG, "out is NULL");
+    *out = nullptr;
+    int rc = validate(nullptr, params);
+    if (rc != SPH_OK) return rc;
+
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        return fail(nullptr, SPH_E_HIP, "no HIP device available (%s); libsph_hip has no CPU fallback",
+                    e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+    if (params->device_id < 0 || params->device_id >= ndev)
+        return fail(nullptr, SPH_E_INVALID_ARG, "device_id %d not in [0,%d)", params->device_id, ndev);
+
+    SphContext *c = new SphContext();
+    c->params = *params;
+    c->device = params->device_id;
+    c->profile = (params->flags & SPH_FLAG_PROFILE) != 0;
+    derive(c->params, &c->derived);
+    refresh_scalars(c);
+
+    auto bail = [&](int code) {
+        std::string msg = c->last_error;
+        sph_destroy(c);
+        g_last_error = msg;
+        return code;
+    };
+    if (hipSetDevice(c->device) != hipSuccess) {
+        fail(c, SPH_E_HIP, "hipSetDevice(%d) failed", c->device);
+        return bail(SPH_E_HIP);
+    }
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+        fail(c, SPH_E_HIP, "hipStreamCreate failed");
+        return bail(SPH_E_HIP);
+    }
+    c->own_stream = true;
+
+    Dev &d = c->dev;
+    const size_t n = d.count;
+    const size_t cells = (size_t)d.num_cells + 2;
+    const size_t scan_blocks = (cells + 4095) / 4096 + 1;
+#define A(expr)                         \
+    if ((rc = (expr)) != SPH_OK) return bail(rc)
+    A(alloc_soa(c, &d.cur, n));
+    A(alloc_soa(c, &d.nxt, n));
+    A(dalloc(c, &d.id, n));
+    A(dalloc(c, &d.id_nxt, n));
+    A(dalloc(c, &d.rho, n));
+    A(dalloc(c, &d.rho_nxt, n));
+    A(dalloc(c, &d.key, n));
+    A(dalloc(c, &d.cell_count, cells));
+    A(dalloc(c, &d.cell_start, cells));
+    A(dalloc(c, &d.order, 2 * n));
+    A(dalloc(c, &d.block_sums, scan_blocks));
+    A(dalloc(c, &d.counters, (size_t)kCntCount));
+    A(dalloc(c, &c->pos4_dev, n));
+    A(dalloc(c, &c->vel4_dev, n));
+    A(dalloc(c, &c->rho_id_dev, n));
+    A(dalloc(c, &c->pw0, n));
+#undef A
+    if (hipMemsetAsync(d.counters, 0, sizeof(unsigned long long) * kCntCount, c->stream) != hipSuccess ||
+        hipMemsetAsync(d.cell_count, 0, sizeof(uint32_t) * cells, c->stream) != hipSuccess ||
+        hipMemsetAsync(d.cell_start, 0, sizeof(uint32_t) * cells, c->stream) != hipSuccess ||
+        hipStreamSynchronize(c->stream) != hipSuccess) {
+        fail(c, SPH_E_HIP, "device memset failed");
+        return bail(SPH_E_HIP);
+    }
+    *out = c;
+    return SPH_OK;
+}
+
+int sph_destroy(SphContext *c)
+{
+    if (!c) return SPH_OK;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    fold_events(c);
+    for (hipEvent_t e : c->free_events) (void)hipEventDestroy(e);
+    for (void *p : c->allocs) (void)hipFree(p);
+    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return SPH_OK;
+}
+
+int sph_upload(SphContext *c, const float *pos4, const float *vel4)
+{
+    if (!c) return fail(nullptr, SPH_E_INVALID_ARG, "ctx is NULL");
+    if (!pos4) return fail(c, SPH_E_INVALID_ARG, "pos4 is NULL");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t bytes = (size_t)c->dev.count * sizeof(float4);
+    HIP_TRY(c, hipMemcpyAsync(c->pos4_dev, pos4, bytes, hipMemcpyHostToDevice, c->stream));
+    if (vel4) HIP_TRY(c, hipMemcpyAsync(c->vel4_dev, vel4, bytes, hipMemcpyHostToDevice, c->stream));
+    launch_upload_split(c->dev, c->pos4_dev, vel4 ? c->vel4_dev : nullptr, c->pw0, c->stream);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipStreamSynchronize(c->stream));  // the caller's arrays may be freed on return
+    c->uploaded = true;
+    c->grid_valid = false;
+    c->substeps_since_upload = 0;
+    return SPH_OK;
+}
+
+int sph_download(SphContext *c, float *pos4, float *vel4, float *rho)
+{
+    if (!c) return fail(nullptr, SPH_E_INVALID_ARG, "ctx is NULL");
+    if (!c->uploaded) return fail(c, SPH_E_BAD_STATE, "sph_download before sph_upload");
+    HIP_TRY(c, hipSetDevice(c->device));
+    launch_download_merge(c->dev, c->pw0, c->substeps_since_upload, c->dt_last, pos4 ? c->pos4_dev : nullptr,
+                          vel4 ? c->vel4_dev : nullptr, rho ? c->rho_id_dev : nullptr, c->stream);
+    HIP_TRY(c, hipGetLastError());
+    const size_t n = c->dev.count;
+    if (pos4) HIP_TRY(c, hipMemcpyAsync(pos4, c->pos4_dev, n * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
+    if (vel4) HIP_TRY(c, hipMemcpyAsync(vel4, c->vel4_dev, n * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
+    if (rho) HIP_TRY(c, hipMemcpyAsync(rho, c->rho_id_dev, n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return SPH_OK;
+}
+
+int sph_bucket_generation(SphContext *c)
+{
+    if (!c) return fail(nullptr, SPH_E_INVALID_ARG, "ctx is NULL");
+    HIP_TRY(c, hipSetDevice(c->device));
+    return do_bucket_generation(c);
+}
+
+int sph_density_calculation(SphContext *c)
+{
+    if (!c) return fail(nullptr, SPH_E_INVALID_ARG, "ctx is NULL");
+    HIP_TRY(c, hipSetDevice(c->device));
+    return do_density(c);
+}
+
+int sph_update_velocity_and_position(SphContext *c, float dt)
+{
+    if (!c) return fail(nullptr, SPH_E_INVALID_ARG, "ctx is NULL");
+    HIP_TRY(c, hipSetDevice(c->device));
+    return do_velpos(c, dt);
+}
+
+int sph_step(SphContext *c, float delta_time)
+{
+    if (!c) return fail(nullptr, SPH_E_INVALID_ARG, "ctx is NULL");
+    HIP_TRY(c, hipSetDevice(c->device));
+    int rc;
+    if ((rc = do_bucket_generation(c)) != SPH_OK) return rc;            // :98
+    if ((rc = do_density(c)) != SPH_OK) return rc;                      // :99
+    const float dt = delta_time / c->params.dt_divisor;                 // :102 Time.deltaTime / 25
+    for (uint32_t i = 0; i < c->params.substeps; i++)                   // :101
+        if ((rc = do_velpos(c, dt)) != SPH_OK) return rc;
+    return SPH_OK;
+}
+
+int sph_step_n(SphContext *c, float delta_time, int frames)
+{
+    if (frames < 0) return fail(c, SPH_E_INVALID_ARG, "frames < 0");
+    for (int f = 0; f < frames; f++) {
+        int rc = sph_step(c, delta_time);
+        if (rc != SPH_OK) return rc;
+    }
+    return SPH_OK;
+}
+
+int sph_set_params(SphContext *c, const SphParams *p)
+{
+    if (!c) return fail(nullptr, SPH_E_INVALID_ARG, "ctx is NULL");
+    int rc = validate(c, p);
+    if (rc != SPH_OK) return rc;
+    if (next_power_of_two(p->num_particles) != c->derived.num_particles || p->bucket_resolution != c->params.bucket_resolution ||
+        p->dam_fill_rate != c->params.dam_fill_rate || p->device_id != c->params.device_id)
+        return fail(c, SPH_E_INVALID_ARG,
+                    "num_particles / bucket_resolution / dam_fill_rate / device_id are fixed at sph_create");
+    c->params = *p;
+    c->profile = (p->flags & SPH_FLAG_PROFILE) != 0;
+    refresh_scalars(c);
+    return SPH_OK;
+}
+
+int sph_get_derived(SphContext *c, SphDerived *out)
+{
+    if (!c || !out) return fail(c, SPH_E_INVALID_ARG, "NULL argument");
+    *out = c->derived;
+    return SPH_OK;
+}
+
+int sph_synchronize(SphContext *c)
+{
+    if (!c) return fail(nullptr, SPH_E_INVALID_ARG, "ctx is NULL");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return SPH_OK;
+}
+
+int sph_get_stats(SphContext *c, SphStats *out)
+{
+    if (!c || !out) return fail(c, SPH_E_INVALID_ARG, "NULL argument");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    fold_events(c);
+    unsigned long long cnt[kCntCount];
+    HIP_TRY(c, hipMemcpy(cnt, c->dev.counters, sizeof cnt, hipMemcpyDeviceToHost));
+    memset(out, 0, sizeof *out);
+    out->frames = c->frames;
+    out->substeps = c->substeps;
+    out->ms_grid = c->ms[0];
+    out->ms_density = c->ms[1];
+    out->ms_velpos = c->ms[2];
+    out->launches_grid = c->launches[0];
+    out->launches_density = c->launches[1];
+    out->launches_velpos = c->launches[2];
+    out->max_cell_occupancy = (uint32_t)cnt[kCntMaxOcc];
+    out->overflowed_cells = (uint32_t)cnt[kCntOverflowCells];
+    out->dropped_particles = (uint32_t)cnt[kCntDropped];
+    out->nan_resets = cnt[kCntNaN];
+    out->candidates_density = cnt[kCntCandidates];
+    return SPH_OK;
+}
+
+int sph_reset_stats(SphContext *c)
+{
+    if (!c) return fail(nullptr, SPH_E_INVALID_ARG, "ctx is NULL");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    fold_events(c);
+    for (int i = 0; i < 3; i++) {
+        c->ms[i] = 0;
+        c->launches[i] = 0;
+    }
+    return SPH_OK;
+}
+
+int sph_set_stream(SphContext *c, void *hip_stream)
+{
+    if (!c) return fail(nullptr, SPH_E_INVALID_ARG, "ctx is NULL");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    fold_events(c);
+    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    c->stream = (hipStream_t)hip_stream;
+    c->own_stream = false;
+    return SPH_OK;
+}
+
+const char *sph_last_error(SphContext *c)
+{
+    if (c) return c->last_error.c_str();
+    return g_last_error.c_str();
+}
+
+}  // extern "C"

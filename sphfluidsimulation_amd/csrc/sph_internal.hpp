@@ -1,0 +1,89 @@
+// Internal declarations shared by the HIP translation units of libsph_hip.so (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace sph {
+
+constexpr uint32_t kMaxPerVoxel = 32;  // MaxParticlesPerVoxel, SphFluidSimulation.cs:9
+constexpr int kWave = 64;              // CDNA4 wavefront
+
+// One set of cell-sorted SoA particle arrays (ping-pong partner of another set).
+struct Soa {
+    float *x, *y, *z;     // position (pos.w is derived, see k_download)
+    float *vx, *vy, *vz;  // velocity
+    float *vw;            // vel.w: sub-step counter / 0.003 NaN marker (VelPos.compute:146,150)
+};
+
+// Everything a kernel needs, passed by value.
+struct Dev {
+    uint32_t count;        // live particles = res*res
+    uint32_t sentinel_n;   // _NumParticles
+    uint32_t R;            // _BucketResolution
+    uint32_t num_cells;    // R^3 ; cell index num_cells is the "limbo" cell of dropped particles
+    float Rm1;             // float(R-1)
+    float Rf;              // float(R)
+    float mass, h, h2, h9;
+    float c_poly6;         // 315/(64*pi)           Density.compute:23
+    float c_over_h6;       // (45/pi)/h^6           VelPos.compute:37,43
+    float viscosity, gas_const, rest_density, stiffness, damping;
+    float gx, gy, gz;
+    float dt;
+    Soa cur, nxt;
+    uint32_t *id;          // slot -> particle id (texel y*res + x); fixed for a whole frame
+    uint32_t *id_nxt;      // written by the reorder, swapped with id after a grid build
+    float *rho;            // by slot (_ParticleDensityTexture)
+    float *rho_nxt;        // reorder target, swapped with rho after a grid build
+    uint32_t *key;         // by slot (of cur, before the reorder)
+    uint32_t *cell_count;  // [num_cells+1]
+    uint32_t *cell_start;  // [num_cells+2] exclusive prefix of cell_count
+    uint2 *order;          // [count] (particle id, source slot) in new slot order
+    uint32_t *block_sums;  // scan scratch
+    unsigned long long *counters;  // device statistics, see Counter
+};
+
+enum Counter : int {
+    kCntNaN = 0,        // NaN-guard hits
+    kCntCandidates,     // candidates visited by the density pass
+    kCntMaxOcc,         // max cell occupancy (atomicMax)
+    kCntOverflowCells,  // cells with > 32 members
+    kCntDropped,        // particles whose linear cell index is outside the bucket
+    kCntCount
+};
+
+// ---- HLSL conversion semantics (identical to oracle/sph_oracle.c) -----------------------------
+__device__ __forceinline__ int hlsl_int(float f)
+{
+    if (f != f) return 0;
+    if (f <= -2147483648.0f) return INT32_MIN;
+    if (f >= 2147483648.0f) return INT32_MAX;
+    return (int)f;
+}
+__device__ __forceinline__ uint32_t hlsl_uint(float f)
+{
+    if (!(f > 0.0f)) return 0u;
+    if (f >= 4294967296.0f) return 0xFFFFFFFFu;
+    return (uint32_t)f;
+}
+__device__ __forceinline__ float clamp01(float x) { return fminf(fmaxf(x, 0.0f), 1.0f); }
+
+// Cell coordinate of a position component: float3 idx_3d = int3(pos * (R-1))
+// (Bucket.compute:27, Density.compute:39, VelPos.compute:58).  Returned clamped to [-2, R+1]:
+// every coordinate outside that range behaves the same in the 27-cell sweep (all three
+// neighbours fail the bounds test of Density.compute:46 / VelPos.compute:73).
+__device__ __forceinline__ int cell_coord(float p, float Rm1, int R)
+{
+    int c = hlsl_int(p * Rm1);
+    return c < -2 ? -2 : (c > R + 1 ? R + 1 : c);
+}
+
+// launchers (sph_kernels_*.hip)
+void launch_upload_split(const Dev &d, const float4 *pos4, const float4 *vel4, float *pw0, hipStream_t s);
+void launch_download_merge(const Dev &d, const float *pw0, int substeps_done, float dt_last,
+                           float4 *pos4, float4 *vel4, float *rho_by_id, hipStream_t s);
+void launch_grid_build(const Dev &d, hipStream_t s);  // keys, histogram, scan, scatter, id-sort, reorder: cur -> nxt
+void launch_density(const Dev &d, hipStream_t s);
+void launch_velpos(const Dev &d, hipStream_t s);      // cur -> nxt
+
+}  // namespace sph

@@ -1,0 +1,266 @@
+// Uniform-grid build for gfx950: replaces Bucket.compute::ClearBucket (:38-53) and ::CSMain (:15-36).
+//
+// The reference keeps a 32-slot table per cell (128 B/cell, R^3 cells) filled by a CAS race.  Here
+// the particles themselves are kept in CELL-SORTED SoA order, rebuilt once per frame:
+//   key/histogram -> exclusive scan (cell_start) -> scatter -> id-rank inside each cell -> gather.
+// Inside a cell, slots are in ASCENDING PARTICLE ID (= a serial execution of Bucket.compute:30-35),
+// so "the first min(count,32) slots of the cell" is exactly the reference's bucket row
+// (SURVEY.md 9.2).  Particles whose linear cell index falls outside the bucket
+// go to a "limbo" cell (index R^3) that no sweep ever reads.
+#include "sph_internal.hpp"
+
+namespace sph {
+
+constexpr int kBlock = 256;
+constexpr int kScanThreads = 1024;
+constexpr int kScanItems = 4;                          // per thread
+constexpr int kScanTile = kScanThreads * kScanItems;   // per block
+
+// ---- AoS (reference texture layout) <-> SoA ---------------------------------------------------
+
+__global__ void __launch_bounds__(kBlock) k_upload_split(Dev d, const float4 *__restrict__ pos4,
+                                                         const float4 *__restrict__ vel4,
+                                                         float *__restrict__ pw0)
+{
+    const uint32_t p = blockIdx.x * kBlock + threadIdx.x;
+    if (p >= d.count) return;
+    const float4 q = pos4[p];
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);        // ClearFloat4, SphFluidSimulation.cs:189
+    if (vel4) v = vel4[p];
+    d.cur.x[p] = q.x; d.cur.y[p] = q.y; d.cur.z[p] = q.z;
+    d.cur.vx[p] = v.x; d.cur.vy[p] = v.y; d.cur.vz[p] = v.z; d.cur.vw[p] = v.w;
+    d.id[p] = p;                                       // id = y*res + x, Bucket.compute:24
+    pw0[p] = q.w;
+    d.rho[p] = 0.0f;
+}
+
+__global__ void __launch_bounds__(kBlock) k_download_merge(Dev d, const float *__restrict__ pw0,
+                                                           int substeps_done, float dt_last,
+                                                           float4 *__restrict__ pos4,
+                                                           float4 *__restrict__ vel4,
+                                                           float *__restrict__ rho_by_id)
+{
+    const uint32_t s = blockIdx.x * kBlock + threadIdx.x;
+    if (s >= d.count) return;
+    const uint32_t id = d.id[s];
+    const float vw = d.cur.vw[s];
+    // VelPos.compute:153-154: pos_out.w = clamp(1 + dt*vel_out.w, 0, 1); the uploaded w before that
+    const float pw = substeps_done > 0 ? clamp01(1.0f + dt_last * vw) : pw0[id];
+    if (pos4) pos4[id] = make_float4(d.cur.x[s], d.cur.y[s], d.cur.z[s], pw);
+    if (vel4) vel4[id] = make_float4(d.cur.vx[s], d.cur.vy[s], d.cur.vz[s], vw);
+    if (rho_by_id) rho_by_id[id] = d.rho[s];
+}
+
+// ---- cell key + histogram: Bucket.compute:26-29 ------------------------------------------------
+
+__global__ void __launch_bounds__(kBlock) k_cell_key_hist(Dev d)
+{
+    const uint32_t p = blockIdx.x * kBlock + threadIdx.x;
+    if (p >= d.count) return;
+    // :27 float3 idx_3d = int3(pos * (R-1))
+    const float ix = (float)hlsl_int(d.cur.x[p] * d.Rm1);
+    const float iy = (float)hlsl_int(d.cur.y[p] * d.Rm1);
+    const float iz = (float)hlsl_int(d.cur.z[p] * d.Rm1);
+    // :28 evaluated in float, then converted to uint; :29 index *= 32 in uint
+    uint32_t index = hlsl_uint((ix + iy * d.Rf) + iz * d.Rf * d.Rf);
+    index *= kMaxPerVoxel;
+    const unsigned long long len = (unsigned long long)d.num_cells * kMaxPerVoxel;
+    const uint32_t key = (unsigned long long)index < len ? index / kMaxPerVoxel : d.num_cells;
+    d.key[p] = key;
+    atomicAdd(&d.cell_count[key], 1u);
+}
+
+// ---- exclusive scan of cell_count[0 .. n) -> cell_start[0 .. n], n = num_cells + 1 ------------
+
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v)
+{
+    const int lane = threadIdx.x & (kWave - 1);
+#pragma unroll
+    for (int o = 1; o < kWave; o <<= 1) {
+        const uint32_t t = __shfl_up(v, o, kWave);
+        if (lane >= o) v += t;
+    }
+    return v;
+}
+
+// exclusive scan of one value per thread across a 1024-thread block; returns block total in *total
+__device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *lds_wave_tot, uint32_t *total)
+{
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    const uint32_t incl = wave_incl_scan(v);
+    if (lane == kWave - 1) lds_wave_tot[wave] = incl;
+    __syncthreads();
+    if (wave == 0) {
+        uint32_t t = lane < (kScanThreads / kWave) ? lds_wave_tot[lane] : 0u;
+        const uint32_t ti = wave_incl_scan(t);
+        if (lane < (kScanThreads / kWave)) lds_wave_tot[lane] = ti - t;  // exclusive wave offsets
+        if (lane == kWave - 1) lds_wave_tot[kScanThreads / kWave] = ti;   // block total
+    }
+    __syncthreads();
+    *total = lds_wave_tot[kScanThreads / kWave];
+    return lds_wave_tot[wave] + incl - v;
+}
+
+__global__ void __launch_bounds__(kScanThreads) k_scan_reduce(Dev d, uint32_t n)
+{
+    __shared__ uint32_t lds[kScanThreads / kWave + 1];
+    const uint32_t base = blockIdx.x * kScanTile + threadIdx.x * kScanItems;
+    uint32_t sum = 0, mx = 0, over = 0;
+#pragma unroll
+    for (int i = 0; i < kScanItems; i++) {
+        const uint32_t idx = base + i;
+        if (idx < n) {
+            const uint32_t c = d.cell_count[idx];
+            sum += c;
+            if (idx < d.num_cells) {                    // statistics exclude the limbo cell
+                mx = c > mx ? c : mx;
+                over += c > kMaxPerVoxel ? 1u : 0u;
+            }
+        }
+    }
+    uint32_t total;
+    block_excl_scan(sum, lds, &total);
+    if (threadIdx.x == 0) d.block_sums[blockIdx.x] = total;
+    // per-wave reduction of the statistics, one atomic per wave
+#pragma unroll
+    for (int o = kWave / 2; o > 0; o >>= 1) {
+        const uint32_t m2 = __shfl_down(mx, o, kWave);
+        mx = m2 > mx ? m2 : mx;
+        over += __shfl_down(over, o, kWave);
+    }
+    if ((threadIdx.x & (kWave - 1)) == 0) {
+        if (mx) atomicMax(&d.counters[kCntMaxOcc], (unsigned long long)mx);
+        if (over) atomicAdd(&d.counters[kCntOverflowCells], (unsigned long long)over);
+    }
+}
+
+__global__ void __launch_bounds__(kScanThreads) k_scan_blocksums(Dev d, uint32_t nb)
+{
+    __shared__ uint32_t lds[kScanThreads / kWave + 1];
+    const uint32_t per = (nb + kScanThreads - 1) / kScanThreads;
+    const uint32_t b0 = threadIdx.x * per;
+    uint32_t sum = 0;
+    for (uint32_t i = 0; i < per; i++)
+        if (b0 + i < nb) sum += d.block_sums[b0 + i];
+    uint32_t total;
+    uint32_t run = block_excl_scan(sum, lds, &total);
+    for (uint32_t i = 0; i < per; i++)
+        if (b0 + i < nb) {
+            const uint32_t v = d.block_sums[b0 + i];
+            d.block_sums[b0 + i] = run;
+            run += v;
+        }
+}
+
+__global__ void __launch_bounds__(kScanThreads) k_scan_final(Dev d, uint32_t n)
+{
+    __shared__ uint32_t lds[kScanThreads / kWave + 1];
+    const uint32_t base = blockIdx.x * kScanTile + threadIdx.x * kScanItems;
+    uint32_t c[kScanItems];
+    uint32_t sum = 0;
+#pragma unroll
+    for (int i = 0; i < kScanItems; i++) {
+        c[i] = (base + i < n) ? d.cell_count[base + i] : 0u;
+        sum += c[i];
+    }
+    uint32_t total;
+    uint32_t run = block_excl_scan(sum, lds, &total) + d.block_sums[blockIdx.x];
+#pragma unroll
+    for (int i = 0; i < kScanItems; i++) {
+        if (base + i < n) d.cell_start[base + i] = run;
+        run += c[i];
+        if (base + i == n - 1) {
+            d.cell_start[n] = run;                      // == count
+            d.counters[kCntDropped] = c[i];             // members of the limbo cell
+        }
+    }
+}
+
+// ---- scatter: unordered slot inside the cell (atomicSub leaves cell_count all zero) -----------
+
+__global__ void __launch_bounds__(kBlock) k_scatter(Dev d, uint2 *__restrict__ order_tmp)
+{
+    const uint32_t p = blockIdx.x * kBlock + threadIdx.x;
+    if (p >= d.count) return;
+    const uint32_t key = d.key[p];
+    const uint32_t off = atomicSub(&d.cell_count[key], 1u) - 1u;
+    order_tmp[d.cell_start[key] + off] = make_uint2(d.id[p], p);
+}
+
+// ---- ascending-id order inside each cell (the CAS race made deterministic) ---------------------
+// One thread per element: rank = number of same-cell elements with a smaller particle id, counted
+// up to 32.  rank < 32  -> slot = rank (the visible part of the cell, exact order);
+// rank >= 32 -> invisible to every sweep (Bucket.compute:30-35 gave up on it): any unique slot
+// behind the first 32 will do, taken from a per-cell ticket (cell_count is zero after k_scatter
+// and is memset again at the start of the next build).
+
+__global__ void __launch_bounds__(kBlock) k_cell_rank(Dev d, const uint2 *__restrict__ order_tmp)
+{
+    const uint32_t t = blockIdx.x * kBlock + threadIdx.x;
+    if (t >= d.count) return;
+    const uint2 me = order_tmp[t];
+    const uint32_t key = d.key[me.y];
+    if (key == d.num_cells) {                           // limbo: never read by a sweep, keep as is
+        d.order[t] = me;
+        return;
+    }
+    const uint32_t start = d.cell_start[key];
+    const uint32_t cnt = d.cell_start[key + 1] - start;
+    uint32_t rank = 0;
+    for (uint32_t k = 0; k < cnt && rank < kMaxPerVoxel; k++)
+        rank += order_tmp[start + k].x < me.x ? 1u : 0u;
+    uint32_t slot = rank;
+    if (rank >= kMaxPerVoxel) slot = kMaxPerVoxel + atomicAdd(&d.cell_count[key], 1u);
+    d.order[start + slot] = me;
+}
+
+// ---- gather the payload into the new order: cur -> nxt ----------------------------------------
+
+__global__ void __launch_bounds__(kBlock) k_reorder(Dev d)
+{
+    const uint32_t s = blockIdx.x * kBlock + threadIdx.x;
+    if (s >= d.count) return;
+    const uint2 o = d.order[s];
+    const uint32_t src = o.y;
+    d.nxt.x[s] = d.cur.x[src]; d.nxt.y[s] = d.cur.y[src]; d.nxt.z[s] = d.cur.z[src];
+    d.nxt.vx[s] = d.cur.vx[src]; d.nxt.vy[s] = d.cur.vy[src]; d.nxt.vz[s] = d.cur.vz[src];
+    d.nxt.vw[s] = d.cur.vw[src];
+    d.rho_nxt[s] = d.rho[src];                         // the density texture persists by id
+    d.id_nxt[s] = o.x;
+}
+
+// ---- launchers ---------------------------------------------------------------------------------
+
+static inline uint32_t cdiv(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
+
+void launch_upload_split(const Dev &d, const float4 *pos4, const float4 *vel4, float *pw0, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_upload_split, dim3(cdiv(d.count, kBlock)), dim3(kBlock), 0, s, d, pos4, vel4, pw0);
+}
+
+void launch_download_merge(const Dev &d, const float *pw0, int substeps_done, float dt_last,
+                           float4 *pos4, float4 *vel4, float *rho_by_id, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_download_merge, dim3(cdiv(d.count, kBlock)), dim3(kBlock), 0, s, d, pw0,
+                       substeps_done, dt_last, pos4, vel4, rho_by_id);
+}
+
+void launch_grid_build(const Dev &d, hipStream_t s)
+{
+    const uint32_t n = d.num_cells + 1;                // + limbo
+    const uint32_t nb = cdiv(n, kScanTile);
+    const uint32_t pb = cdiv(d.count, kBlock);
+    // order_tmp lives behind order (allocated 2*count)
+    uint2 *order_tmp = d.order + d.count;
+    (void)hipMemsetAsync(d.cell_count, 0, sizeof(uint32_t) * (size_t)n, s);
+    (void)hipMemsetAsync(d.counters + kCntMaxOcc, 0, sizeof(unsigned long long) * 3, s);
+    hipLaunchKernelGGL(k_cell_key_hist, dim3(pb), dim3(kBlock), 0, s, d);
+    hipLaunchKernelGGL(k_scan_reduce, dim3(nb), dim3(kScanThreads), 0, s, d, n);
+    hipLaunchKernelGGL(k_scan_blocksums, dim3(1), dim3(kScanThreads), 0, s, d, nb);
+    hipLaunchKernelGGL(k_scan_final, dim3(nb), dim3(kScanThreads), 0, s, d, n);
+    hipLaunchKernelGGL(k_scatter, dim3(pb), dim3(kBlock), 0, s, d, order_tmp);
+    hipLaunchKernelGGL(k_cell_rank, dim3(pb), dim3(kBlock), 0, s, d, (const uint2 *)order_tmp);
+    hipLaunchKernelGGL(k_reorder, dim3(pb), dim3(kBlock), 0, s, d);
+}
+
+}  // namespace sph

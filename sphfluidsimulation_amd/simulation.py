@@ -1,0 +1,160 @@
+"""Host-side mirror of the reference driver, Assets/Scripts/SphFluidSimulation.cs, over the C ABI.
+
+Same public field names (inspector fields :35-45), same method names and meaning
+(Start :82, Update :96, OnDestroy :110, BucketGeneration :203, DensityCalculation :223,
+UpdateVelocityAndPosition :243), so tests read like the reference driver.  Every method goes
+through libsph_hip.so (include/sph_hip.h); there is no CPU path here.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _native as N
+from . import presets
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float)) if a is not None else None
+
+
+class SphFluidSimulation:
+    # constants, SphFluidSimulation.cs:8-9
+    NumThreads = 32
+    MaxParticlesPerVoxel = 32
+
+    def __init__(self, preset: int = 1, particleNumber: int = 1024, bucketResolution: int = 256,
+                 damFillRate: float = 0.5, viscosity: float = 0.01, restDensity: float = 1.5,
+                 gasConstant: float = 150.0, stiffnessCoefficient: float = 5000.0,
+                 dampingCoefficient: float = 10.0, device_id: int = 0, profile: bool = False):
+        # inspector fields and defaults, SphFluidSimulation.cs:35-45
+        self.preset = preset
+        self.particleNumber = particleNumber
+        self.bucketResolution = bucketResolution
+        self.damFillRate = damFillRate
+        self.viscosity = viscosity
+        self.restDensity = restDensity
+        self.gasConstant = gasConstant
+        self.stiffnessCoefficient = stiffnessCoefficient
+        self.dampingCoefficient = dampingCoefficient
+        self.device_id = device_id
+        self.profile = profile
+        self._ctx = C.c_void_p()
+        self._derived = None
+
+    # ---- parameter plumbing -------------------------------------------------------------------
+    def _params(self) -> N.SphParams:
+        p = N.default_params()
+        p.num_particles = int(self.particleNumber)
+        p.bucket_resolution = int(self.bucketResolution)
+        p.dam_fill_rate = self.damFillRate
+        p.viscosity = self.viscosity
+        p.rest_density = self.restDensity
+        p.gas_constant = self.gasConstant
+        p.stiffness_coeff = self.stiffnessCoefficient
+        p.damping_coeff = self.dampingCoefficient
+        p.device_id = self.device_id
+        p.flags = N.SPH_FLAG_PROFILE if self.profile else 0
+        return p
+
+    def _check(self, rc):
+        N.check(rc, self._ctx)
+
+    # ---- Unity functions ----------------------------------------------------------------------
+    def Start(self, positions: np.ndarray | None = None, velocities: np.ndarray | None = None,
+              seed: int = 1):
+        """SphFluidSimulation.cs:82-94.  The reference fills the position texture with
+        InitParticles.compute (kernel index = preset) and clears the velocity texture; here the
+        caller passes the float4 arrays, or gets the synthetic dam-break of presets.dam_break
+        (Preset1 lattice, hash jitter)."""
+        p = self._params()
+        self._check(N.lib().sph_create(C.byref(p), C.byref(self._ctx)))
+        d = N.SphDerived()
+        self._check(N.lib().sph_get_derived(self._ctx, C.byref(d)))
+        self._derived = d
+        self.particleNumber = d.num_particles                    # :84
+        self._particleTextureResolution = d.particle_resolution  # :85
+        self._effectiveRadius = d.effective_radius               # :159
+        self._particleMass = d.particle_mass                     # :176
+        if positions is None:
+            positions, velocities = presets.dam_break(self.particleNumber, self.damFillRate, seed)
+        self.upload(positions, velocities)
+        return self
+
+    def Update(self, deltaTime: float):
+        """SphFluidSimulation.cs:96-102 (render hooks :104-107 are out of scope)."""
+        self._check(N.lib().sph_step(self._ctx, float(np.float32(deltaTime))))
+
+    def OnDestroy(self):
+        """SphFluidSimulation.cs:110-120."""
+        if self._ctx:
+            N.lib().sph_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    close = OnDestroy
+
+    def __del__(self):
+        try:
+            self.OnDestroy()
+        except Exception:
+            pass
+
+    # ---- Update region ------------------------------------------------------------------------
+    def BucketGeneration(self):
+        self._check(N.lib().sph_bucket_generation(self._ctx))
+
+    def DensityCalculation(self):
+        self._check(N.lib().sph_density_calculation(self._ctx))
+
+    def UpdateVelocityAndPosition(self, dt: float):
+        self._check(N.lib().sph_update_velocity_and_position(self._ctx, float(np.float32(dt))))
+
+    # ---- data in / out (the reference never reads back; the drop-in must) ---------------------
+    @property
+    def count(self) -> int:
+        return int(self._derived.particle_count)
+
+    @property
+    def derived(self) -> N.SphDerived:
+        return self._derived
+
+    def upload(self, positions: np.ndarray, velocities: np.ndarray | None = None):
+        pos = np.ascontiguousarray(positions, np.float32).reshape(-1, 4)
+        if pos.shape[0] != self.count:
+            raise ValueError(f"positions must hold {self.count} float4, got {pos.shape[0]}")
+        vel = None
+        if velocities is not None:
+            vel = np.ascontiguousarray(velocities, np.float32).reshape(-1, 4)
+            if vel.shape[0] != self.count:
+                raise ValueError(f"velocities must hold {self.count} float4, got {vel.shape[0]}")
+        self._check(N.lib().sph_upload(self._ctx, _fp(pos), _fp(vel)))
+
+    def download(self):
+        pos = np.empty((self.count, 4), np.float32)
+        vel = np.empty((self.count, 4), np.float32)
+        rho = np.empty((self.count,), np.float32)
+        self._check(N.lib().sph_download(self._ctx, _fp(pos), _fp(vel), _fp(rho)))
+        return pos, vel, rho
+
+    def step_n(self, deltaTime: float, frames: int):
+        self._check(N.lib().sph_step_n(self._ctx, float(np.float32(deltaTime)), int(frames)))
+
+    def set_params(self):
+        """Push changed inspector scalars (viscosity .. dampingCoefficient) mid-run."""
+        p = self._params()
+        self._check(N.lib().sph_set_params(self._ctx, C.byref(p)))
+
+    def synchronize(self):
+        self._check(N.lib().sph_synchronize(self._ctx))
+
+    def stats(self) -> dict:
+        s = N.SphStats()
+        self._check(N.lib().sph_get_stats(self._ctx, C.byref(s)))
+        return s.as_dict()
+
+    def reset_stats(self):
+        self._check(N.lib().sph_reset_stats(self._ctx))
+
+    def set_stream(self, hip_stream: int):
+        self._check(N.lib().sph_set_stream(self._ctx, C.c_void_p(hip_stream)))

@@ -1,0 +1,98 @@
+"""CPU-side checks of the drop-in boundary: libsph_hip.so builds for gfx950, loads, exports every
+symbol include/sph_hip.h declares, and refuses to run without a GPU (no CPU fallback).
+No compute call is made here."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def native():
+    from sphfluidsimulation_amd import build
+    build.build()                       # hipcc cross-compiles gfx950 without a GPU
+    from sphfluidsimulation_amd import _native
+    _native.lib()
+    return _native
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "sph_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(sph_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_header_symbols_are_exported_and_bound(native):
+    names = declared_symbols()
+    assert len(names) >= 18
+    assert sorted(native.SYMBOLS) == names          # the ctypes binding covers the whole header
+    raw = C.CDLL(native.LIB_PATH)
+    for n in names:
+        assert hasattr(raw, n), f"{n} not exported by libsph_hip.so"
+
+
+def test_struct_layouts_match_header(native):
+    # 4-byte members only, no padding (blittable for C# LayoutKind.Sequential)
+    assert C.sizeof(native.SphParams) == 19 * 4
+    p = native.default_params()
+    assert p.struct_size == C.sizeof(native.SphParams)
+    # inspector defaults SphFluidSimulation.cs:35-45 and the hard-coded constants :9,:101-102
+    assert (p.num_particles, p.bucket_resolution, p.max_per_voxel, p.substeps) == (1024, 256, 32, 5)
+    assert abs(p.dam_fill_rate - 0.5) < 1e-7 and abs(p.viscosity - 0.01) < 1e-8
+    assert (p.rest_density, p.gas_constant, p.stiffness_coeff, p.damping_coeff) == (1.5, 150.0, 5000.0, 10.0)
+    assert p.dt_divisor == 25.0 and abs(p.gravity[1] + 9.8) < 1e-6 and p.gravity[0] == 0 and p.gravity[2] == 0
+    assert C.sizeof(native.SphDerived) == 9 * 4
+    assert C.sizeof(native.SphStats) == 8 * 8 + 4 * 4 + 2 * 8
+    assert native.lib().sph_version() == 1
+
+
+def test_argument_validation_without_gpu(native):
+    L = native.lib()
+    ctx = C.c_void_p()
+    p = native.default_params()
+    p.struct_size = 12
+    assert L.sph_create(C.byref(p), C.byref(ctx)) == native.SPH_E_INVALID_ARG
+    assert b"struct_size" in L.sph_last_error(None)
+    p = native.default_params()
+    p.bucket_resolution = 1
+    assert L.sph_create(C.byref(p), C.byref(ctx)) == native.SPH_E_INVALID_ARG
+    p = native.default_params()
+    p.max_per_voxel = 16
+    assert L.sph_create(C.byref(p), C.byref(ctx)) == native.SPH_E_UNSUPPORTED
+    assert L.sph_create(None, C.byref(ctx)) == native.SPH_E_INVALID_ARG
+    assert L.sph_step(None, 0.01) == native.SPH_E_INVALID_ARG
+    assert L.sph_destroy(None) == native.SPH_OK
+
+
+def test_no_cpu_fallback(native):
+    """On a box without a GPU the engine must fail loudly, never compute on the host."""
+    import subprocess
+    import sys
+    code = (
+        "import ctypes as C, sys; sys.path.insert(0, %r)\n"
+        "from sphfluidsimulation_amd import _native as N\n"
+        "p = N.default_params(); ctx = C.c_void_p()\n"
+        "rc = N.lib().sph_create(C.byref(p), C.byref(ctx))\n"
+        "print(rc, N.lib().sph_last_error(None).decode())\n" % ROOT)
+    env = dict(os.environ, HIP_VISIBLE_DEVICES="-1", ROCR_VISIBLE_DEVICES="-1")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=120)
+    assert out.returncode == 0, out.stderr
+    rc, msg = out.stdout.strip().split(" ", 1)
+    assert int(rc) == native.SPH_E_HIP and "no CPU fallback" in msg
+    from sphfluidsimulation_amd.simulation import SphFluidSimulation  # noqa: F401  (imports without a GPU)
+
+
+def test_product_does_not_use_the_oracle():
+    """oracle/ is test infrastructure: the shipped package must not import, load or link it."""
+    pkg = os.path.join(ROOT, "sphfluidsimulation_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if not f.endswith((".py", ".hip", ".hpp", ".cpp", ".h")):
+                continue
+            text = open(os.path.join(dirpath, f)).read()
+            assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), f
+            assert "libsph_oracle" not in text and "sph_oracle.py" not in text, f
+            assert not re.search(r"#include\s+[\"<].*oracle", text), f
