@@ -104,6 +104,7 @@ static void refresh_scalars(SphContext *c)
     d.h = dv.effective_radius;
     d.h2 = dv.effective_radius2;
     d.h9 = dv.effective_radius9;
+    d.h2_up = nextafterf((float)((double)d.h * (double)d.h * (1.0 + 1e-5)), INFINITY);
     d.c_poly6 = 315.0f / (64.0f * PI);                        // Density.compute:23
     d.c_over_h6 = (45.0f / PI) / dv.effective_radius6;        // VelPos.compute:34,37,41,43
     d.viscosity = p.viscosity;
@@ -230,6 +231,7 @@ static int do_density(SphContext *c)
         launch_density(c->dev, c->stream);
     }
     HIP_TRY(c, hipGetLastError());
+    c->dev.force_slow = 0;  // the pressure flag now matches the current gas_const / rest_density
     return SPH_OK;
 }
 
@@ -243,6 +245,7 @@ static int do_velpos(SphContext *c, float dt)
     }
     HIP_TRY(c, hipGetLastError());
     std::swap(c->dev.cur, c->dev.nxt);  // Swap(), SphFluidSimulation.cs:267-268
+    c->dev.wild_v_cur ^= 1u;
     c->substeps++;
     c->substeps_since_upload++;
     c->dt_last = dt;
@@ -374,6 +377,9 @@ int sph_upload(SphContext *c, const float *pos4, const float *vel4)
     const size_t bytes = (size_t)c->dev.count * sizeof(float4);
     HIP_TRY(c, hipMemcpyAsync(c->pos4_dev, pos4, bytes, hipMemcpyHostToDevice, c->stream));
     if (vel4) HIP_TRY(c, hipMemcpyAsync(c->vel4_dev, vel4, bytes, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->dev.counters + kCntWildP, 0, sizeof(unsigned long long) * 3, c->stream));
+    c->dev.wild_v_cur = 0;
+    c->dev.force_slow = 0;
     launch_upload_split(c->dev, c->pos4_dev, vel4 ? c->vel4_dev : nullptr, c->pw0, c->stream);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipStreamSynchronize(c->stream));  // the caller's arrays may be freed on return
@@ -452,6 +458,8 @@ int sph_set_params(SphContext *c, const SphParams *p)
         p->dam_fill_rate != c->params.dam_fill_rate || p->device_id != c->params.device_id)
         return fail(c, SPH_E_INVALID_ARG,
                     "num_particles / bucket_resolution / dam_fill_rate / device_id are fixed at sph_create");
+    if (p->gas_constant != c->params.gas_constant || p->rest_density != c->params.rest_density)
+        c->dev.force_slow = 1;  // pressures change without a density pass: flag is stale until the next one
     c->params = *p;
     c->profile = (p->flags & SPH_FLAG_PROFILE) != 0;
     refresh_scalars(c);

@@ -25,11 +25,14 @@ struct Dev {
     float Rm1;             // float(R-1)
     float Rf;              // float(R)
     float mass, h, h2, h9;
+    float h2_up;           // h^2 * (1 + 1e-5): conservative pre-filter for |r| < h
     float c_poly6;         // 315/(64*pi)           Density.compute:23
     float c_over_h6;       // (45/pi)/h^6           VelPos.compute:37,43
     float viscosity, gas_const, rest_density, stiffness, damping;
     float gx, gy, gz;
     float dt;
+    uint32_t force_slow;   // 1: take the literal one-phase VelPos loop (set by sph_set_params)
+    uint32_t wild_v_cur;   // which kCntWildV slot describes the velocities in `cur`
     Soa cur, nxt;
     uint32_t *id;          // slot -> particle id (texel y*res + x); fixed for a whole frame
     uint32_t *id_nxt;      // written by the reorder, swapped with id after a grid build
@@ -49,6 +52,9 @@ enum Counter : int {
     kCntMaxOcc,         // max cell occupancy (atomicMax)
     kCntOverflowCells,  // cells with > 32 members
     kCntDropped,        // particles whose linear cell index is outside the bucket
+    kCntWildP,          // some pressure k*(rho-rho0) is >= 1e15, inf or NaN (set by the density pass)
+    kCntWildV0,         // some velocity component is >= 1e15, inf or NaN (two slots, ping-pong)
+    kCntWildV1,
     kCntCount
 };
 

@@ -32,6 +32,8 @@ __global__ void __launch_bounds__(kBlock) k_upload_split(Dev d, const float4 *__
     d.id[p] = p;                                       // id = y*res + x, Bucket.compute:24
     pw0[p] = q.w;
     d.rho[p] = 0.0f;
+    if (!(fabsf(v.x) < 1e15f) || !(fabsf(v.y) < 1e15f) || !(fabsf(v.z) < 1e15f))
+        d.counters[kCntWildV0 + d.wild_v_cur] = 1ull;   // see sph_kernels_sweep.hip
 }
 
 __global__ void __launch_bounds__(kBlock) k_download_merge(Dev d, const float *__restrict__ pw0,

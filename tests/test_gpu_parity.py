@@ -31,8 +31,9 @@ def engine(n, R, fill=0.8, **kw):
 def assert_parity(got, want, name, exact=True):
     got, want = np.asarray(got), np.asarray(want)
     assert got.shape == want.shape, name
-    both_nan = np.isnan(got) & np.isnan(want)
-    diff = np.where(both_nan, 0.0, np.abs(got.astype(np.float64) - want.astype(np.float64)))
+    same = (got == want) | (np.isnan(got) & np.isnan(want))     # inf == inf, NaN == NaN, -0 == +0
+    with np.errstate(invalid="ignore", over="ignore"):
+        diff = np.where(same, 0.0, np.abs(got.astype(np.float64) - want.astype(np.float64)))
     diff = np.where(np.isnan(diff), np.inf, diff)
     scale = max(1.0, float(np.nanmax(np.abs(np.where(np.isfinite(want), want, 0.0)))))
     worst = float(diff.max()) if diff.size else 0.0
