@@ -139,6 +139,7 @@ def main():
                       "velpos": vel_ms},
         "particle_substeps_per_s": value * 5,
         "max_cell_occupancy": st["max_cell_occupancy"], "nan_resets": st["nan_resets"],
+        "queued_targets_last_sweep": st["queued_targets"],
     }
     if not a.no_cpu_baseline:
         base, (po, vo, ro) = cpu_baseline(n, R, fill, pos0, vel0, dt_frame)

@@ -72,6 +72,7 @@ typedef struct SphParams {
 } SphParams;
 
 #define SPH_FLAG_PROFILE 1u     /* record HIP events around every pass (SphStats.ms_*)            */
+#define SPH_FLAG_NO_TILING 2u   /* diagnostic: per-target kernels on global memory, no LDS bricks */
 
 /* Values of the uniforms the reference pushes through ShaderIDs.cs:5-32. */
 typedef struct SphDerived {
@@ -100,7 +101,8 @@ typedef struct SphStats {
     uint32_t max_cell_occupancy; /* before the 32-cap                                            */
     uint32_t overflowed_cells;   /* cells holding more than max_per_voxel particles              */
     uint32_t dropped_particles;  /* linear cell index outside the bucket         */
-    uint32_t reserved0;
+    uint32_t queued_targets;     /* targets the LDS-tiled kernel handed to the generic kernel in
+                                    the last sweep (moved > 1 cell, out of grid, tile overflow)  */
     uint64_t nan_resets;         /* NaN-guard hits (VelPos.compute:143-147) since create         */
     uint64_t candidates_density; /* listed candidates visited by the last density pass (P-bar*N) */
 } SphStats;

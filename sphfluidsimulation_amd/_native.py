@@ -16,6 +16,7 @@ SPH_E_HIP = -4
 SPH_E_UNSUPPORTED = -5
 SPH_E_COMM = -6
 SPH_FLAG_PROFILE = 1
+SPH_FLAG_NO_TILING = 2
 
 _ERR_NAMES = {
     SPH_E_INVALID_ARG: "SPH_E_INVALID_ARG", SPH_E_BAD_STATE: "SPH_E_BAD_STATE", SPH_E_OOM: "SPH_E_OOM",
@@ -78,7 +79,7 @@ class SphStats(C.Structure):
         ("max_cell_occupancy", C.c_uint32),
         ("overflowed_cells", C.c_uint32),
         ("dropped_particles", C.c_uint32),
-        ("reserved0", C.c_uint32),
+        ("queued_targets", C.c_uint32),
         ("nan_resets", C.c_uint64),
         ("candidates_density", C.c_uint64),
     ]

@@ -115,6 +115,7 @@ static void refresh_scalars(SphContext *c)
     d.gx = p.gravity[0];
     d.gy = p.gravity[1];
     d.gz = p.gravity[2];
+    d.use_bricks = (p.flags & SPH_FLAG_NO_TILING) ? 0u : 1u;
 }
 
 static int validate(SphContext *ctx, const SphParams *p)
@@ -339,6 +340,7 @@ int sph_create(const SphParams *params, SphContext **out)
     A(dalloc(c, &d.cell_start, cells));
     A(dalloc(c, &d.order, 2 * n));
     A(dalloc(c, &d.block_sums, scan_blocks));
+    A(dalloc(c, &d.queue, n));
     A(dalloc(c, &d.counters, (size_t)kCntCount));
     A(dalloc(c, &c->pos4_dev, n));
     A(dalloc(c, &c->vel4_dev, n));
@@ -501,6 +503,7 @@ int sph_get_stats(SphContext *c, SphStats *out)
     out->max_cell_occupancy = (uint32_t)cnt[kCntMaxOcc];
     out->overflowed_cells = (uint32_t)cnt[kCntOverflowCells];
     out->dropped_particles = (uint32_t)cnt[kCntDropped];
+    out->queued_targets = (uint32_t)cnt[kCntQueue];
     out->nan_resets = cnt[kCntNaN];
     out->candidates_density = cnt[kCntCandidates];
     return SPH_OK;

@@ -33,6 +33,7 @@ struct Dev {
     float dt;
     uint32_t force_slow;   // 1: take the literal one-phase VelPos loop (set by sph_set_params)
     uint32_t wild_v_cur;   // which kCntWildV slot describes the velocities in `cur`
+    uint32_t use_bricks;   // 1: LDS-tiled brick kernels + queue; 0: per-target kernels on global memory
     Soa cur, nxt;
     uint32_t *id;          // slot -> particle id (texel y*res + x); fixed for a whole frame
     uint32_t *id_nxt;      // written by the reorder, swapped with id after a grid build
@@ -43,6 +44,7 @@ struct Dev {
     uint32_t *cell_start;  // [num_cells+2] exclusive prefix of cell_count
     uint2 *order;          // [count] (particle id, source slot) in new slot order
     uint32_t *block_sums;  // scan scratch
+    uint32_t *queue;       // [count] target slots handed from the brick kernels to the generic kernels
     unsigned long long *counters;  // device statistics, see Counter
 };
 
@@ -55,6 +57,7 @@ enum Counter : int {
     kCntWildP,          // some pressure k*(rho-rho0) is >= 1e15, inf or NaN (set by the density pass)
     kCntWildV0,         // some velocity component is >= 1e15, inf or NaN (two slots, ping-pong)
     kCntWildV1,
+    kCntQueue,          // length of `queue` for the pass in flight
     kCntCount
 };
 
@@ -89,7 +92,7 @@ void launch_upload_split(const Dev &d, const float4 *pos4, const float4 *vel4, f
 void launch_download_merge(const Dev &d, const float *pw0, int substeps_done, float dt_last,
                            float4 *pos4, float4 *vel4, float *rho_by_id, hipStream_t s);
 void launch_grid_build(const Dev &d, hipStream_t s);  // keys, histogram, scan, scatter, id-sort, reorder: cur -> nxt
-void launch_density(const Dev &d, hipStream_t s);
+void launch_density(const Dev &d, hipStream_t s);     // sph_kernels_brick.hip (tiled) + queue
 void launch_velpos(const Dev &d, hipStream_t s);      // cur -> nxt
 
 }  // namespace sph

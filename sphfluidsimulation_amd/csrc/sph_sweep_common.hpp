@@ -1,0 +1,148 @@
+// Device code shared by the sweep kernels (sph_kernels_sweep.hip: per-target kernels on global
+// memory; sph_kernels_brick.hip: LDS-tiled brick kernels).  Every function evaluates the
+// reference's statements one IEEE fp32 operation at a time, in source order
+// (Density.compute:22-27, VelPos.compute:33-44,86-157) -- see oracle/sph_oracle.c for the contract.
+#pragma once
+
+#include "sph_internal.hpp"
+
+namespace sph {
+
+constexpr float kWildLimit = 1e15f;
+
+__device__ __forceinline__ bool is_wild(float v) { return !(fabsf(v) < kWildLimit); }
+
+struct CellRange {
+    uint32_t start, cnt;
+};
+
+// Bounds test of Density.compute:46 / VelPos.compute:73 + the bucket row of that cell:
+// the first min(count, 32) slots, ascending particle id.
+__device__ __forceinline__ CellRange cell_range(const Dev &d, int jx, int jy, int jz)
+{
+    CellRange r{0u, 0u};
+    const int R = (int)d.R;
+    if (jx >= 0 && jy >= 0 && jz >= 0 && jx < R && jy < R && jz < R) {
+        const uint32_t c = (uint32_t)jx + (uint32_t)jy * d.R + (uint32_t)jz * d.R * d.R;
+        r.start = d.cell_start[c];
+        const uint32_t n = d.cell_start[c + 1] - r.start;
+        r.cnt = n < kMaxPerVoxel ? n : kMaxPerVoxel;
+    }
+    return r;
+}
+
+// Density.compute:22-27 W() times _ParticleMass (:54)
+__device__ __forceinline__ float density_term(const Dev &d, float rx, float ry, float rz)
+{
+    const float abs_r2 = (rx * rx + ry * ry) + rz * rz;                          // :24
+    const float diff_r2 = d.h2 - abs_r2;                                         // :25
+    const float w = 0.0f < diff_r2 ? d.c_poly6 * ((diff_r2 * diff_r2) * diff_r2) / d.h9 : 0.0f; // :26
+    return d.mass * w;                                                           // :54
+}
+
+struct Force {
+    float px, py, pz;  // f_press
+    float vx, vy, vz;  // f_vis
+};
+
+// VelPos.compute:86-95 for one listed candidate j != i whose fields are already in registers.
+__device__ __forceinline__ void pair_force_vals(const Dev &d, float rx, float ry, float rz, float rho_j,
+                                                float vjx, float vjy, float vjz, float vix, float viy,
+                                                float viz, float p_i, Force &f)
+{
+    const float epsilon = 1e-6f;                                                 // :5
+    const float h = d.h;
+    const float p_j = d.gas_const * (rho_j - d.rest_density);                    // :87
+    if (rho_j > epsilon) {                                                       // :91
+        const float abs_r = sqrtf((rx * rx + ry * ry) + rz * rz);                // :35, :42
+        const float diff_r = h - abs_r;                                          // :36
+        float gpx = 0.0f, gpy = 0.0f, gpz = 0.0f;
+        if ((epsilon < diff_r) && (epsilon < abs_r)) {                           // :37
+            const float sc = d.c_over_h6 * ((diff_r * diff_r) * diff_r);
+            gpx = (sc * rx) / abs_r;
+            gpy = (sc * ry) / abs_r;
+            gpz = (sc * rz) / abs_r;
+        }
+        const float cp = (p_i + p_j) / (2.0f * rho_j);                           // :93
+        f.px += cp * gpx;
+        f.py += cp * gpy;
+        f.pz += cp * gpz;
+        const float gv = abs_r < h ? d.c_over_h6 * (h - abs_r) : 0.0f;           // :43
+        f.vx += ((vjx - vix) / rho_j) * gv;                                      // :94
+        f.vy += ((vjy - viy) / rho_j) * gv;
+        f.vz += ((vjz - viz) / rho_j) * gv;
+    }
+}
+
+__device__ __forceinline__ void pair_force(const Dev &d, uint32_t j, float pix, float piy, float piz,
+                                           float vix, float viy, float viz, float p_i, Force &f)
+{
+    pair_force_vals(d, pix - d.cur.x[j], piy - d.cur.y[j], piz - d.cur.z[j], d.rho[j], d.cur.vx[j],
+                    d.cur.vy[j], d.cur.vz[j], vix, viy, viz, p_i, f);            // :86-89
+}
+
+// VelPos.compute:100-157: scaling, wall force, NaN guard, integrate, clamp, store.
+__device__ __forceinline__ void integrate_store(const Dev &d, uint32_t s, float pix, float piy, float piz,
+                                                float vix, float viy, float viz, float viw, float rho_i,
+                                                Force f)
+{
+    const float epsilon = 1e-6f;
+    const float h = d.h, m = d.mass;
+    if (rho_i > epsilon) {                                                       // :101
+        const float sp = m * m / rho_i;                                          // :103
+        f.px *= sp; f.py *= sp; f.pz *= sp;
+        const float sv = d.viscosity * m * m / rho_i;                            // :104
+        f.vx *= sv; f.vy *= sv; f.vz *= sv;
+    }
+    float fwx = 0.0f, fwy = 0.0f, fwz = 0.0f;                                    // :107
+    float wrx = 0.0f, wry = 0.0f, wrz = 0.0f;                                    // :108
+    if (pix < h) wrx += h - pix;                                                 // :110-113
+    else if (pix > 1.0f - h) wrx += 1.0f - pix - h;
+    if (piy < h) wry += h - piy;                                                 // :115-118
+    else if (piy > 1.0f - h) wry += 1.0f - piy - h;
+    if (piz < h) wrz += h - piz;                                                 // :120-123
+    else if (piz > 1.0f - h) wrz += 1.0f - piz - h;
+    const float max_r = fmaxf(fabsf(wrx), fmaxf(fabsf(wry), fabsf(wrz)));        // :125-126
+    const float dpx = (wrx != 0.0f) ? d.damping : 0.0f;                          // :128-131
+    const float dpy = (wry != 0.0f) ? d.damping : 0.0f;
+    const float dpz = (wrz != 0.0f) ? d.damping : 0.0f;
+    if (max_r > 0.0f) {                                                          // :133
+        const float dd = (dpx * vix + dpy * viy) + dpz * viz;                    // :135 scalar
+        fwx = wrx * d.stiffness - dd;
+        fwy = wry * d.stiffness - dd;
+        fwz = wrz * d.stiffness - dd;
+        fwx *= m; fwy *= m; fwz *= m;                                            // :136
+    }
+    const float ax = d.gx + ((f.px + f.vx) + fwx) / m;                           // :139
+    const float ay = d.gy + ((f.py + f.vy) + fwy) / m;
+    const float az = d.gz + ((f.pz + f.vz) + fwz) / m;
+    float vox, voy, voz, vow;
+    if (ax != ax || ay != ay || az != az) {                                      // :143
+        vox = 0.0f; voy = 0.0f; voz = 0.0f; vow = 0.003f;                        // :145-146
+        atomicAdd(&d.counters[kCntNaN], 1ull);
+    } else {
+        vox = vix + ax * d.dt;                                                   // :150
+        voy = viy + ay * d.dt;
+        voz = viz + az * d.dt;
+        vow = viw + 1.0f;
+    }
+    d.nxt.x[s] = clamp01(pix + d.dt * vox);                                      // :153-154
+    d.nxt.y[s] = clamp01(piy + d.dt * voy);
+    d.nxt.z[s] = clamp01(piz + d.dt * voz);
+    d.nxt.vx[s] = vox; d.nxt.vy[s] = voy; d.nxt.vz[s] = voz; d.nxt.vw[s] = vow;  // :156-157
+    if (is_wild(vox) || is_wild(voy) || is_wild(voz)) d.counters[kCntWildV0 + (d.wild_v_cur ^ 1)] = 1ull;
+}
+
+__device__ __forceinline__ bool launch_is_wild(const Dev &d)
+{
+    return d.force_slow != 0u || d.counters[kCntWildP] != 0ull || d.counters[kCntWildV0 + d.wild_v_cur] != 0ull;
+}
+
+__device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
+{
+#pragma unroll
+    for (int o = kWave / 2; o > 0; o >>= 1) v += __shfl_down(v, o, kWave);
+    return v;
+}
+
+}  // namespace sph

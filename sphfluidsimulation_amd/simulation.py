@@ -27,7 +27,8 @@ class SphFluidSimulation:
     def __init__(self, preset: int = 1, particleNumber: int = 1024, bucketResolution: int = 256,
                  damFillRate: float = 0.5, viscosity: float = 0.01, restDensity: float = 1.5,
                  gasConstant: float = 150.0, stiffnessCoefficient: float = 5000.0,
-                 dampingCoefficient: float = 10.0, device_id: int = 0, profile: bool = False):
+                 dampingCoefficient: float = 10.0, device_id: int = 0, profile: bool = False,
+                 tiling: bool = True):
         # inspector fields and defaults, SphFluidSimulation.cs:35-45
         self.preset = preset
         self.particleNumber = particleNumber
@@ -40,6 +41,7 @@ class SphFluidSimulation:
         self.dampingCoefficient = dampingCoefficient
         self.device_id = device_id
         self.profile = profile
+        self.tiling = tiling            # False: diagnostic per-target kernels (SPH_FLAG_NO_TILING)
         self._ctx = C.c_void_p()
         self._derived = None
 
@@ -55,7 +57,7 @@ class SphFluidSimulation:
         p.stiffness_coeff = self.stiffnessCoefficient
         p.damping_coeff = self.dampingCoefficient
         p.device_id = self.device_id
-        p.flags = N.SPH_FLAG_PROFILE if self.profile else 0
+        p.flags = (N.SPH_FLAG_PROFILE if self.profile else 0) | (0 if self.tiling else N.SPH_FLAG_NO_TILING)
         return p
 
     def _check(self, rc):
