@@ -45,7 +45,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not needs_build():
         return LIB
     os.makedirs(LIB_DIR, exist_ok=True)
-    cmd = [hipcc()] + FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB]
+    extra = os.environ.get("SPH_HIPCC_EXTRA", "").split()   # diagnostic builds, e.g. -DSPH_ABLATE=1
+    cmd = [hipcc()] + FLAGS + extra + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)

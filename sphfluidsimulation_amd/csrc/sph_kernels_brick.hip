@@ -19,10 +19,14 @@
 // survivors per target from L2.
 #include "sph_sweep_common.hpp"
 
+#ifndef SPH_ABLATE
+#define SPH_ABLATE 0
+#endif
+
 namespace sph {
 
 constexpr int BX = 8, BY = 4, BZ = 4;  // owned cells per brick
-constexpr int kT = 256;                // threads per brick
+constexpr int kT = 512;                // threads per brick
 constexpr int kRows = BY * BZ;
 
 template <int H>
@@ -98,6 +102,15 @@ __device__ __forceinline__ uint32_t target_slot(const uint32_t *row_start, const
     return row_start[r] + (t - row_pref[r]);
 }
 
+// LDS index of halo cell (cx,cy,cz): z runs fastest, so the reference's innermost loop (z_offset,
+// Density.compute:44 / VelPos.compute:69) walks ONE contiguous LDS run per (x_offset, y_offset).
+template <int H>
+__device__ __forceinline__ int hcz(const BrickGeom g, int cx, int cy, int cz)
+{
+    using HB = Halo<H>;
+    return (cz - (g.z0 - H)) + HB::HZ * ((cy - (g.y0 - H)) + HB::HY * (cx - (g.x0 - H)));
+}
+
 // Common set-up: owned rows, halo cell table, staging of positions.  Returns the number of owned
 // particles (0: nothing to do or everything was queued).
 template <int H, int CAP>
@@ -133,25 +146,37 @@ __device__ __forceinline__ uint32_t brick_setup(const Dev &d, const BrickGeom g,
     const uint32_t Tn = s_row_pref[kRows];
     if (Tn == 0) return 0;
 
-    // halo cell table
-    uint32_t cnt[HB::PER], g0[HB::PER], sum = 0;
+    // A: bucket rows of the halo cells, threads x-fastest (coalesced cell_start reads)
+    uint32_t cnt[HB::PER], g0[HB::PER];
+    int lds_cell[HB::PER];
 #pragma unroll
     for (int i = 0; i < HB::PER; i++) {
-        const int hc = (int)tid * HB::PER + i;
+        const int a = (int)tid * HB::PER + i;
         cnt[i] = 0;
         g0[i] = 0;
-        if (hc < HB::NH) {
-            const int cx = g.x0 - H + hc % HB::HX, cy = g.y0 - H + (hc / HB::HX) % HB::HY,
-                      cz = g.z0 - H + hc / (HB::HX * HB::HY);
+        lds_cell[i] = -1;
+        if (a < HB::NH) {
+            const int cx = g.x0 - H + a % HB::HX, cy = g.y0 - H + (a / HB::HX) % HB::HY,
+                      cz = g.z0 - H + a / (HB::HX * HB::HY);
             if (cx >= 0 && cy >= 0 && cz >= 0 && cx < R && cy < R && cz < R) {
                 const uint32_t key = (uint32_t)cx + (uint32_t)cy * d.R + (uint32_t)cz * d.R * d.R;
-                const uint32_t a = d.cell_start[key];
-                const uint32_t n = d.cell_start[key + 1] - a;
+                const uint32_t st = d.cell_start[key];
+                const uint32_t n = d.cell_start[key + 1] - st;
                 cnt[i] = n < kMaxPerVoxel ? n : kMaxPerVoxel;
-                g0[i] = a;
+                g0[i] = st;
             }
+            lds_cell[i] = hcz<H>(g, cx, cy, cz);
+            s_info[lds_cell[i]] = cnt[i];
+            s_g0[lds_cell[i]] = g0[i];
         }
-        sum += cnt[i];
+    }
+    __syncthreads();
+    // B: LDS offsets in z-fastest cell order
+    uint32_t sum = 0;
+#pragma unroll
+    for (int i = 0; i < HB::PER; i++) {
+        const int b = (int)tid * HB::PER + i;
+        if (b < HB::NH) sum += s_info[b];
     }
     uint32_t total;
     uint32_t run = brick_excl_scan(sum, s_scan, &total);
@@ -161,20 +186,50 @@ __device__ __forceinline__ uint32_t brick_setup(const Dev &d, const BrickGeom g,
     }
 #pragma unroll
     for (int i = 0; i < HB::PER; i++) {
-        const int hc = (int)tid * HB::PER + i;
-        if (hc < HB::NH) {
-            s_info[hc] = run | (cnt[i] << 16);
-            s_g0[hc] = g0[i];
+        const int b = (int)tid * HB::PER + i;
+        if (b < HB::NH) {
+            const uint32_t c = s_info[b];
+            s_info[b] = run | (c << 16);
+            run += c;
+        }
+    }
+    __syncthreads();
+    // C: copy the listed particles, threads x-fastest again (coalesced global reads)
+#pragma unroll
+    for (int i = 0; i < HB::PER; i++) {
+        if (lds_cell[i] >= 0) {
+            const uint32_t base = s_info[lds_cell[i]] & 0xFFFFu;
             for (uint32_t k = 0; k < cnt[i]; k++) {
-                sx[run + k] = d.cur.x[g0[i] + k];
-                sy[run + k] = d.cur.y[g0[i] + k];
-                sz[run + k] = d.cur.z[g0[i] + k];
+                sx[base + k] = d.cur.x[g0[i] + k];
+                sy[base + k] = d.cur.y[g0[i] + k];
+                sz[base + k] = d.cur.z[g0[i] + k];
             }
-            run += cnt[i];
         }
     }
     __syncthreads();
     return Tn;
+}
+
+// One (x_offset, y_offset) column of the 27-cell stencil: the in-grid cells (cx, cy, iz-1..iz+1)
+// form one contiguous LDS run [base, base+cnt) in reference order (z_offset ascending, slots ascending).
+struct Run {
+    uint32_t base, cnt;
+    int first;  // LDS cell index of the first in-grid cell of the run
+};
+
+template <int H>
+__device__ __forceinline__ Run stencil_run(const BrickGeom g, const uint32_t *s_info, int cx, int cy, int iz, int R)
+{
+    Run r{0u, 0u, 0};
+    const int zlo = iz - 1 > 0 ? iz - 1 : 0;
+    const int zhi = iz + 1 < R - 1 ? iz + 1 : R - 1;
+    if (cx >= 0 && cy >= 0 && cx < R && cy < R && zlo <= zhi) {   // Density.compute:46 / VelPos.compute:73
+        r.first = hcz<H>(g, cx, cy, zlo);
+        const uint32_t a = s_info[r.first], b = s_info[r.first + (zhi - zlo)];
+        r.base = a & 0xFFFFu;
+        r.cnt = (b & 0xFFFFu) + (b >> 16) - r.base;
+    }
+    return r;
 }
 
 // ---- Density.compute:29-60 ---------------------------------------------------------------------
@@ -183,7 +238,7 @@ template <int H, int CAP>
 __global__ void __launch_bounds__(kT) k_density_brick(Dev d, int nbx, int nby)
 {
     using HB = Halo<H>;
-    __shared__ float sx[CAP], sy[CAP], sz[CAP];
+    __shared__ float sx[CAP + 4], sy[CAP + 4], sz[CAP + 4];   // +4: the unrolled scan may read past a run
     __shared__ uint32_t s_info[HB::NH], s_g0[HB::NH];
     __shared__ uint32_t s_row_start[kRows], s_row_pref[kRows + 1], s_scan[kT / kWave + 1];
 
@@ -203,17 +258,21 @@ __global__ void __launch_bounds__(kT) k_density_brick(Dev d, int nbx, int nby)
             continue;
         }
         float rho = 0.0f;                                                        // :41
-        for (int xo = -1; xo <= 1; xo++)                                         // :42-44
-            for (int yo = -1; yo <= 1; yo++)
-                for (int zo = -1; zo <= 1; zo++) {
-                    const int cx = ix + xo, cy = iy + yo, cz = iz + zo;
-                    if (cx < 0 || cy < 0 || cz < 0 || cx >= R || cy >= R || cz >= R) continue;  // :46
-                    const uint32_t inf = s_info[(cx - hx0) + HB::HX * ((cy - hy0) + HB::HY * (cz - hz0))];
-                    const uint32_t base = inf & 0xFFFFu, cnt = inf >> 16;
-                    visited += cnt;
-                    for (uint32_t k = 0; k < cnt; k++)                           // :50-55
-                        rho += density_term(d, pix - sx[base + k], piy - sy[base + k], piz - sz[base + k]);
+        for (int xo = -1; xo <= 1; xo++)                                         // :42
+            for (int yo = -1; yo <= 1; yo++) {                                   // :43
+                const Run r = stencil_run<H>(g, s_info, ix + xo, iy + yo, iz, R); // :44-49, z_offset run
+                visited += r.cnt;
+                for (uint32_t p = 0; p < r.cnt; p += 4) {                        // :50-55, 4 slots per trip
+                    float w[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        const uint32_t idx = r.base + p + u;
+                        w[u] = density_term(d, pix - sx[idx], piy - sy[idx], piz - sz[idx]);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; u++) rho += (p + u < r.cnt) ? w[u] : 0.0f;  // + 0.0f is exact
                 }
+            }
         d.rho[s] = rho;                                                          // :59
         if (is_wild(d.gas_const * (rho - d.rest_density))) d.counters[kCntWildP] = 1ull;
     }
@@ -227,7 +286,7 @@ template <int H, int CAP, int LCAP>
 __global__ void __launch_bounds__(kT) k_velpos_brick(Dev d, int nbx, int nby)
 {
     using HB = Halo<H>;
-    __shared__ float sx[CAP], sy[CAP], sz[CAP];
+    __shared__ float sx[CAP + 4], sy[CAP + 4], sz[CAP + 4];
     __shared__ uint32_t s_info[HB::NH], s_g0[HB::NH];
     __shared__ uint32_t s_row_start[kRows], s_row_pref[kRows + 1], s_scan[kT / kWave + 1];
     __shared__ uint32_t s_list32[(LCAP / 2) * kT];  // u16 entries, dword column = thread
@@ -256,46 +315,80 @@ __global__ void __launch_bounds__(kT) k_velpos_brick(Dev d, int nbx, int nby)
         const float vix = d.cur.vx[s], viy = d.cur.vy[s], viz = d.cur.vz[s], viw = d.cur.vw[s]; // :62
         Force f{0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};                             // :64-65
 
+        // list entry = (column 0..8) << 7 | position in the column's LDS run
+        struct Cand {
+            float x, y, z, rho, vx, vy, vz;
+            bool self;
+        };
+        auto fetch = [&](uint32_t e) {
+            const uint32_t ent = list[(((e >> 1) * kT + tid) << 1) + (e & 1u)];
+            const int c = (int)(ent >> 7);
+            uint32_t k = ent & 127u;
+            const int zlo = iz - 1 > 0 ? iz - 1 : 0;
+            int hc = hcz<H>(g, ix + c / 3 - 1, iy + c % 3 - 1, zlo);
+            uint32_t inf = s_info[hc];
+            const uint32_t idx = (inf & 0xFFFFu) + k;
+            if (k >= (inf >> 16)) {            // which of the (up to 3) cells of the run
+                k -= inf >> 16;
+                inf = s_info[++hc];
+                if (k >= (inf >> 16)) {
+                    k -= inf >> 16;
+                    ++hc;
+                }
+            }
+            const uint32_t j = s_g0[hc] + k;
+            return Cand{sx[idx], sy[idx], sz[idx], d.rho[j], d.cur.vx[j], d.cur.vy[j], d.cur.vz[j], j == s};
+        };
         // phase 2: pair arithmetic over the listed survivors, in list (= reference) order
         auto phase2 = [&](uint32_t n) {
+#if SPH_ABLATE == 2   /* diagnostic: no phase 2 at all */
+            f.px += (float)n; return;
+#endif
+            if (n == 0) return;
+            Cand a = fetch(0);
             for (uint32_t e = 0; e < n; e++) {
-                const uint32_t ent = list[(((e >> 1) * kT + tid) << 1) + (e & 1u)];
-                const int c = (int)(ent >> 5);
-                const uint32_t k = ent & 31u;
-                const int cx = ix + c / 9 - 1, cy = iy + (c / 3) % 3 - 1, cz = iz + c % 3 - 1;
-                const int hc = (cx - hx0) + HB::HX * ((cy - hy0) + HB::HY * (cz - hz0));
-                const uint32_t idx = (s_info[hc] & 0xFFFFu) + k;
-                const uint32_t j = s_g0[hc] + k;
-                pair_force_vals(d, pix - sx[idx], piy - sy[idx], piz - sz[idx], d.rho[j], d.cur.vx[j],
-                                d.cur.vy[j], d.cur.vz[j], vix, viy, viz, p_i, f);   // :86-95
+                Cand b = a;
+                if (e + 1 < n) b = fetch(e + 1);       // next survivor's gathers fly during the arithmetic
+#if SPH_ABLATE == 1   /* diagnostic: no pair arithmetic */
+                f.px += a.x + a.rho; f.py += a.y + a.vx; f.pz += a.z + a.vy; f.vx += a.vz;
+#else
+                if (!a.self)                                                      // :82
+                    pair_force_vals(d, pix - a.x, piy - a.y, piz - a.z, a.rho, a.vx, a.vy, a.vz, vix, viy, viz,
+                                    p_i, f);                                      // :86-95
+#endif
+                a = b;
             }
         };
 
-        // phase 1: distance test against LDS, reference order (:67-81)
+        // phase 1: distance test against LDS, reference order (:67-81), 4 slots per trip
         uint32_t n = 0;
-        for (int ci = 0; ci < 27; ci++) {                                        // wave-uniform
-            const int cx = ix + ci / 9 - 1, cy = iy + (ci / 3) % 3 - 1, cz = iz + ci % 3 - 1;
-            uint32_t base = 0, cnt = 0, self_k = 0xFFFFFFFFu;
-            if (live && cx >= 0 && cy >= 0 && cz >= 0 && cx < R && cy < R && cz < R) {  // :73
-                const int hc = (cx - hx0) + HB::HX * ((cy - hy0) + HB::HY * (cz - hz0));
-                const uint32_t inf = s_info[hc];
-                base = inf & 0xFFFFu;
-                cnt = inf >> 16;
-                self_k = s - s_g0[hc];         // :82: k == self_k is the target itself (if listed here)
-            }
-            uint32_t k = 0;
+#if SPH_ABLATE == 3   /* diagnostic: set-up + staging only */
+        for (int c = 0; c < 0; c++) {
+#else
+        for (int c = 0; c < 9; c++) {                                            // wave-uniform
+#endif
+            Run r = stencil_run<H>(g, s_info, ix + c / 3 - 1, iy + c % 3 - 1, iz, R);
+            if (!live) r.cnt = 0;
+            uint32_t p = 0;
             while (true) {
-                while (k < cnt && n < (uint32_t)LCAP) {
-                    const float rx = pix - sx[base + k], ry = piy - sy[base + k], rz = piz - sz[base + k];
-                    const float r2 = (rx * rx + ry * ry) + rz * rz;
-                    if (k != self_k && r2 < d.h2_up) {   // superset of |r| < h (VelPos.compute:37,43)
-                        list[(((n >> 1) * kT + tid) << 1) + (n & 1u)] = (uint16_t)((ci << 5) | k);
-                        n++;
+                while (p < r.cnt && n + 4 <= (uint32_t)LCAP) {
+                    float r2[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        const uint32_t idx = r.base + p + u;
+                        const float rx = pix - sx[idx], ry = piy - sy[idx], rz = piz - sz[idx];
+                        r2[u] = (rx * rx + ry * ry) + rz * rz;
                     }
-                    k++;
+#pragma unroll
+                    for (int u = 0; u < 4; u++)
+                        if (p + u < r.cnt && r2[u] < d.h2_up) {   // superset of |r| < h (VelPos.compute:37,43)
+                            list[(((n >> 1) * kT + tid) << 1) + (n & 1u)] = (uint16_t)((c << 7) | (p + u));
+                            n++;
+                        }
+                    p += 4;
                 }
-                if (!__any(k < cnt)) break;    // every lane finished this cell
-                phase2(n);                     // some lane's list is full: drain all lists
+                if (!__any(p < r.cnt)) break;  // every lane finished this column
+                phase2(n);                     // some lane's list is nearly full: drain all lists
                 n = 0;
             }
         }
