@@ -150,10 +150,10 @@ static int dalloc(SphContext *c, T **out, size_t n)
 static int alloc_soa(SphContext *c, Soa *s, size_t n)
 {
     int rc;
-    float **f[] = {&s->x, &s->y, &s->z, &s->vx, &s->vy, &s->vz, &s->vw};
+    float **f[] = {&s->x, &s->y, &s->z, &s->vw};
     for (auto pp : f)
         if ((rc = dalloc(c, pp, n)) != SPH_OK) return rc;
-    return SPH_OK;
+    return dalloc(c, &s->rv, n);
 }
 
 // ---- profiling events ---------------------------------------------------------------------------
@@ -218,7 +218,6 @@ static int do_bucket_generation(SphContext *c)
     HIP_TRY(c, hipGetLastError());
     std::swap(c->dev.cur, c->dev.nxt);
     std::swap(c->dev.id, c->dev.id_nxt);
-    std::swap(c->dev.rho, c->dev.rho_nxt);
     c->grid_valid = true;
     c->frames++;
     return SPH_OK;
@@ -333,8 +332,6 @@ int sph_create(const SphParams *params, SphContext **out)
     A(alloc_soa(c, &d.nxt, n));
     A(dalloc(c, &d.id, n));
     A(dalloc(c, &d.id_nxt, n));
-    A(dalloc(c, &d.rho, n));
-    A(dalloc(c, &d.rho_nxt, n));
     A(dalloc(c, &d.key, n));
     A(dalloc(c, &d.cell_count, cells));
     A(dalloc(c, &d.cell_start, cells));

@@ -11,8 +11,8 @@ constexpr int kWave = 64;              // CDNA4 wavefront
 
 // One set of cell-sorted SoA particle arrays (ping-pong partner of another set).
 struct Soa {
-    float *x, *y, *z;     // position (pos.w is derived, see k_download)
-    float *vx, *vy, *vz;  // velocity
+    float *x, *y, *z;     // position, SoA: what the neighbour scans stream (pos.w is derived, see k_download)
+    float4 *rv;           // (rho, vx, vy, vz) packed: ONE 16-byte gather per in-range pair in VelPos
     float *vw;            // vel.w: sub-step counter / 0.003 NaN marker (VelPos.compute:146,150)
 };
 
@@ -37,8 +37,6 @@ struct Dev {
     Soa cur, nxt;
     uint32_t *id;          // slot -> particle id (texel y*res + x); fixed for a whole frame
     uint32_t *id_nxt;      // written by the reorder, swapped with id after a grid build
-    float *rho;            // by slot (_ParticleDensityTexture)
-    float *rho_nxt;        // reorder target, swapped with rho after a grid build
     uint32_t *key;         // by slot (of cur, before the reorder)
     uint32_t *cell_count;  // [num_cells+1]
     uint32_t *cell_start;  // [num_cells+2] exclusive prefix of cell_count

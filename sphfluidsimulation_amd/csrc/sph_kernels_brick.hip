@@ -25,15 +25,33 @@
 
 namespace sph {
 
-constexpr int BX = 8, BY = 4, BZ = 4;  // owned cells per brick
-constexpr int kT = 512;                // threads per brick
+// tuning knobs (diagnostic builds override them with -D, see scripts/)
+#ifndef SPH_BRICK_BY
+#define SPH_BRICK_BY 4
+#endif
+#ifndef SPH_VELPOS_T
+#define SPH_VELPOS_T 512
+#endif
+#ifndef SPH_DENSITY_T
+#define SPH_DENSITY_T 256
+#endif
+#ifndef SPH_VELPOS_CAP
+#define SPH_VELPOS_CAP 4096
+#endif
+#ifndef SPH_DENSITY_CAP
+#define SPH_DENSITY_CAP 3072
+#endif
+#ifndef SPH_LCAP
+#define SPH_LCAP 24
+#endif
+constexpr int BX = 8, BY = SPH_BRICK_BY, BZ = 4;  // owned cells per brick
 constexpr int kRows = BY * BZ;
 
-template <int H>
+template <int H, int T = 1>
 struct Halo {
     static constexpr int HX = BX + 2 * H, HY = BY + 2 * H, HZ = BZ + 2 * H;
     static constexpr int NH = HX * HY * HZ;
-    static constexpr int PER = (NH + kT - 1) / kT;  // halo cells per thread during set-up
+    static constexpr int PER = (NH + T - 1) / T;  // halo cells per thread during set-up
 };
 
 __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v)
@@ -47,10 +65,11 @@ __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v)
     return v;
 }
 
-// exclusive scan across the kT threads of a brick; *total = sum.  lds: kT/kWave + 1 words.
+// exclusive scan across the T threads of a brick; *total = sum.  lds: T/kWave + 1 words.
+template <int T>
 __device__ __forceinline__ uint32_t brick_excl_scan(uint32_t v, uint32_t *lds, uint32_t *total)
 {
-    constexpr int NW = kT / kWave;
+    constexpr int NW = T / kWave;
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
     const uint32_t incl = wave_incl_scan_u32(v);
     if (lane == kWave - 1) lds[wave] = incl;
@@ -113,17 +132,17 @@ __device__ __forceinline__ int hcz(const BrickGeom g, int cx, int cy, int cz)
 
 // Common set-up: owned rows, halo cell table, staging of positions.  Returns the number of owned
 // particles (0: nothing to do or everything was queued).
-template <int H, int CAP>
+template <int H, int CAP, int T>
 __device__ __forceinline__ uint32_t brick_setup(const Dev &d, const BrickGeom g, bool force_queue, float *sx,
                                                 float *sy, float *sz, uint32_t *s_info, uint32_t *s_g0,
                                                 uint32_t *s_row_start, uint32_t *s_row_pref, uint32_t *s_scan)
 {
-    using HB = Halo<H>;
+    using HB = Halo<H, T>;
     const uint32_t tid = threadIdx.x;
     const int R = (int)d.R;
 
     if (blockIdx.x == 0)  // limbo particles belong to no brick
-        for (uint32_t t = d.cell_start[d.num_cells] + tid; t < d.count; t += kT) enqueue(d, t);
+        for (uint32_t t = d.cell_start[d.num_cells] + tid; t < d.count; t += T) enqueue(d, t);
 
     if (tid < kRows) {
         const int cy = g.y0 + (int)(tid % BY), cz = g.z0 + (int)(tid / BY);
@@ -179,9 +198,9 @@ __device__ __forceinline__ uint32_t brick_setup(const Dev &d, const BrickGeom g,
         if (b < HB::NH) sum += s_info[b];
     }
     uint32_t total;
-    uint32_t run = brick_excl_scan(sum, s_scan, &total);
+    uint32_t run = brick_excl_scan<T>(sum, s_scan, &total);
     if (force_queue || total > (uint32_t)CAP) {
-        for (uint32_t t = tid; t < Tn; t += kT) enqueue(d, target_slot(s_row_start, s_row_pref, t));
+        for (uint32_t t = tid; t < Tn; t += T) enqueue(d, target_slot(s_row_start, s_row_pref, t));
         return 0;
     }
 #pragma unroll
@@ -234,22 +253,22 @@ __device__ __forceinline__ Run stencil_run(const BrickGeom g, const uint32_t *s_
 
 // ---- Density.compute:29-60 ---------------------------------------------------------------------
 
-template <int H, int CAP>
-__global__ void __launch_bounds__(kT) k_density_brick(Dev d, int nbx, int nby)
+template <int H, int CAP, int T>
+__global__ void __launch_bounds__(T) k_density_brick(Dev d, int nbx, int nby)
 {
-    using HB = Halo<H>;
+    using HB = Halo<H, T>;
     __shared__ float sx[CAP + 4], sy[CAP + 4], sz[CAP + 4];   // +4: the unrolled scan may read past a run
     __shared__ uint32_t s_info[HB::NH], s_g0[HB::NH];
-    __shared__ uint32_t s_row_start[kRows], s_row_pref[kRows + 1], s_scan[kT / kWave + 1];
+    __shared__ uint32_t s_row_start[kRows], s_row_pref[kRows + 1], s_scan[T / kWave + 1];
 
     const BrickGeom g = brick_geom(nbx, nby);
-    const uint32_t Tn = brick_setup<H, CAP>(d, g, false, sx, sy, sz, s_info, s_g0, s_row_start, s_row_pref, s_scan);
+    const uint32_t Tn = brick_setup<H, CAP, T>(d, g, false, sx, sy, sz, s_info, s_g0, s_row_start, s_row_pref, s_scan);
     if (Tn == 0) return;
 
     const int R = (int)d.R;
     const int hx0 = g.x0 - H, hy0 = g.y0 - H, hz0 = g.z0 - H;
     unsigned long long visited = 0;
-    for (uint32_t t = threadIdx.x; t < Tn; t += kT) {
+    for (uint32_t t = threadIdx.x; t < Tn; t += T) {
         const uint32_t s = target_slot(s_row_start, s_row_pref, t);
         const float pix = d.cur.x[s], piy = d.cur.y[s], piz = d.cur.z[s];        // :38
         const int ix = cell_coord(pix, d.Rm1, R), iy = cell_coord(piy, d.Rm1, R), iz = cell_coord(piz, d.Rm1, R);
@@ -273,7 +292,7 @@ __global__ void __launch_bounds__(kT) k_density_brick(Dev d, int nbx, int nby)
                     for (int u = 0; u < 4; u++) rho += (p + u < r.cnt) ? w[u] : 0.0f;  // + 0.0f is exact
                 }
             }
-        d.rho[s] = rho;                                                          // :59
+        d.cur.rv[s].x = rho;                                                     // :59
         if (is_wild(d.gas_const * (rho - d.rest_density))) d.counters[kCntWildP] = 1ull;
     }
     visited = wave_sum_u64(visited);
@@ -282,10 +301,11 @@ __global__ void __launch_bounds__(kT) k_density_brick(Dev d, int nbx, int nby)
 
 // ---- VelPos.compute:46-158 ---------------------------------------------------------------------
 
-template <int H, int CAP, int LCAP>
-__global__ void __launch_bounds__(kT) k_velpos_brick(Dev d, int nbx, int nby)
+template <int H, int CAP, int LCAP, int T>
+__global__ void __launch_bounds__(T) k_velpos_brick(Dev d, int nbx, int nby)
 {
-    using HB = Halo<H>;
+    constexpr int kT = T;
+    using HB = Halo<H, T>;
     __shared__ float sx[CAP + 4], sy[CAP + 4], sz[CAP + 4];
     __shared__ uint32_t s_info[HB::NH], s_g0[HB::NH];
     __shared__ uint32_t s_row_start[kRows], s_row_pref[kRows + 1], s_scan[kT / kWave + 1];
@@ -293,7 +313,7 @@ __global__ void __launch_bounds__(kT) k_velpos_brick(Dev d, int nbx, int nby)
     uint16_t *list = reinterpret_cast<uint16_t *>(s_list32);
 
     const BrickGeom g = brick_geom(nbx, nby);
-    const uint32_t Tn = brick_setup<H, CAP>(d, g, launch_is_wild(d), sx, sy, sz, s_info, s_g0, s_row_start,
+    const uint32_t Tn = brick_setup<H, CAP, T>(d, g, launch_is_wild(d), sx, sy, sz, s_info, s_g0, s_row_start,
                                            s_row_pref, s_scan);
     if (Tn == 0) return;
 
@@ -310,9 +330,10 @@ __global__ void __launch_bounds__(kT) k_velpos_brick(Dev d, int nbx, int nby)
         const bool inside = axis_ok(ix, hx0, HB::HX, R) && axis_ok(iy, hy0, HB::HY, R) && axis_ok(iz, hz0, HB::HZ, R);
         if (live && !inside) enqueue(d, s);
         live = live && inside;                 // dead lanes keep voting but look nothing up
-        const float rho_i = d.rho[s];                                            // :60
+        const float4 rvi = d.cur.rv[s];
+        const float rho_i = rvi.x;                                               // :60
         const float p_i = d.gas_const * (rho_i - d.rest_density);                // :61
-        const float vix = d.cur.vx[s], viy = d.cur.vy[s], viz = d.cur.vz[s], viw = d.cur.vw[s]; // :62
+        const float vix = rvi.y, viy = rvi.z, viz = rvi.w, viw = d.cur.vw[s];    // :62
         Force f{0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};                             // :64-65
 
         // list entry = (column 0..8) << 7 | position in the column's LDS run
@@ -337,7 +358,8 @@ __global__ void __launch_bounds__(kT) k_velpos_brick(Dev d, int nbx, int nby)
                 }
             }
             const uint32_t j = s_g0[hc] + k;
-            return Cand{sx[idx], sy[idx], sz[idx], d.rho[j], d.cur.vx[j], d.cur.vy[j], d.cur.vz[j], j == s};
+            const float4 rv = d.cur.rv[j];     // one 16-byte gather: rho_j, vel_j (:86,:94)
+            return Cand{sx[idx], sy[idx], sz[idx], rv.x, rv.y, rv.z, rv.w, j == s};
         };
         // phase 2: pair arithmetic over the listed survivors, in list (= reference) order
         auto phase2 = [&](uint32_t n) {
@@ -416,7 +438,7 @@ void launch_density(const Dev &d, hipStream_t s)
     }
     (void)hipMemsetAsync(d.counters + kCntQueue, 0, sizeof(unsigned long long), s);
     const uint32_t nbx = cdiv(d.R, BX), nby = cdiv(d.R, BY), nbz = cdiv(d.R, BZ);
-    hipLaunchKernelGGL((k_density_brick<1, 3072>), dim3(nbx * nby * nbz), dim3(kT), 0, s, d, (int)nbx, (int)nby);
+    hipLaunchKernelGGL((k_density_brick<1, SPH_DENSITY_CAP, SPH_DENSITY_T>), dim3(nbx * nby * nbz), dim3(SPH_DENSITY_T), 0, s, d, (int)nbx, (int)nby);
     launch_density_queue(d, s);
 }
 
@@ -430,7 +452,7 @@ void launch_velpos(const Dev &d, hipStream_t s)
     }
     (void)hipMemsetAsync(d.counters + kCntQueue, 0, sizeof(unsigned long long), s);
     const uint32_t nbx = cdiv(d.R, BX), nby = cdiv(d.R, BY), nbz = cdiv(d.R, BZ);
-    hipLaunchKernelGGL((k_velpos_brick<2, 4096, 24>), dim3(nbx * nby * nbz), dim3(kT), 0, s, d, (int)nbx, (int)nby);
+    hipLaunchKernelGGL((k_velpos_brick<2, SPH_VELPOS_CAP, SPH_LCAP, SPH_VELPOS_T>), dim3(nbx * nby * nbz), dim3(SPH_VELPOS_T), 0, s, d, (int)nbx, (int)nby);
     launch_velpos_queue(d, s);
 }
 

@@ -28,10 +28,10 @@ __global__ void __launch_bounds__(kBlock) k_upload_split(Dev d, const float4 *__
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);        // ClearFloat4, SphFluidSimulation.cs:189
     if (vel4) v = vel4[p];
     d.cur.x[p] = q.x; d.cur.y[p] = q.y; d.cur.z[p] = q.z;
-    d.cur.vx[p] = v.x; d.cur.vy[p] = v.y; d.cur.vz[p] = v.z; d.cur.vw[p] = v.w;
+    d.cur.rv[p] = make_float4(0.0f, v.x, v.y, v.z);    // density texture starts cleared
+    d.cur.vw[p] = v.w;
     d.id[p] = p;                                       // id = y*res + x, Bucket.compute:24
     pw0[p] = q.w;
-    d.rho[p] = 0.0f;
     if (!(fabsf(v.x) < 1e15f) || !(fabsf(v.y) < 1e15f) || !(fabsf(v.z) < 1e15f))
         d.counters[kCntWildV0 + d.wild_v_cur] = 1ull;   // see sph_kernels_sweep.hip
 }
@@ -49,8 +49,9 @@ __global__ void __launch_bounds__(kBlock) k_download_merge(Dev d, const float *_
     // VelPos.compute:153-154: pos_out.w = clamp(1 + dt*vel_out.w, 0, 1); the uploaded w before that
     const float pw = substeps_done > 0 ? clamp01(1.0f + dt_last * vw) : pw0[id];
     if (pos4) pos4[id] = make_float4(d.cur.x[s], d.cur.y[s], d.cur.z[s], pw);
-    if (vel4) vel4[id] = make_float4(d.cur.vx[s], d.cur.vy[s], d.cur.vz[s], vw);
-    if (rho_by_id) rho_by_id[id] = d.rho[s];
+    const float4 rv = d.cur.rv[s];
+    if (vel4) vel4[id] = make_float4(rv.y, rv.z, rv.w, vw);
+    if (rho_by_id) rho_by_id[id] = rv.x;
 }
 
 // ---- cell key + histogram: Bucket.compute:26-29 ------------------------------------------------
@@ -225,9 +226,8 @@ __global__ void __launch_bounds__(kBlock) k_reorder(Dev d)
     const uint2 o = d.order[s];
     const uint32_t src = o.y;
     d.nxt.x[s] = d.cur.x[src]; d.nxt.y[s] = d.cur.y[src]; d.nxt.z[s] = d.cur.z[src];
-    d.nxt.vx[s] = d.cur.vx[src]; d.nxt.vy[s] = d.cur.vy[src]; d.nxt.vz[s] = d.cur.vz[src];
+    d.nxt.rv[s] = d.cur.rv[src];                       // the density texture persists by id
     d.nxt.vw[s] = d.cur.vw[src];
-    d.rho_nxt[s] = d.rho[src];                         // the density texture persists by id
     d.id_nxt[s] = o.x;
 }
 

@@ -41,7 +41,7 @@ __device__ __forceinline__ uint32_t density_target(const Dev &d, uint32_t s)
                     rho += density_term(d, pix - d.cur.x[j], piy - d.cur.y[j], piz - d.cur.z[j]);
                 }
             }
-    d.rho[s] = rho;                                                              // :59
+    d.cur.rv[s].x = rho;                                                         // :59
     // pressure that a later VelPos pass derives from this density (VelPos.compute:61,87)
     if (is_wild(d.gas_const * (rho - d.rest_density))) d.counters[kCntWildP] = 1ull;
     return visited;
@@ -54,9 +54,10 @@ __device__ __forceinline__ void velpos_target(const Dev &d, uint32_t s, bool liv
     const float pix = d.cur.x[s], piy = d.cur.y[s], piz = d.cur.z[s];            // :57
     const int R = (int)d.R;
     const int ix = cell_coord(pix, d.Rm1, R), iy = cell_coord(piy, d.Rm1, R), iz = cell_coord(piz, d.Rm1, R);
-    const float rho_i = d.rho[s];                                                // :60
+    const float4 rvi = d.cur.rv[s];
+    const float rho_i = rvi.x;                                                   // :60
     const float p_i = d.gas_const * (rho_i - d.rest_density);                    // :61
-    const float vix = d.cur.vx[s], viy = d.cur.vy[s], viz = d.cur.vz[s], viw = d.cur.vw[s]; // :62
+    const float vix = rvi.y, viy = rvi.z, viz = rvi.w, viw = d.cur.vw[s];        // :62
 
     Force f{0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};                                 // :64-65
 

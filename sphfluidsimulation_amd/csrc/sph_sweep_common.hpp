@@ -77,8 +77,9 @@ __device__ __forceinline__ void pair_force_vals(const Dev &d, float rx, float ry
 __device__ __forceinline__ void pair_force(const Dev &d, uint32_t j, float pix, float piy, float piz,
                                            float vix, float viy, float viz, float p_i, Force &f)
 {
-    pair_force_vals(d, pix - d.cur.x[j], piy - d.cur.y[j], piz - d.cur.z[j], d.rho[j], d.cur.vx[j],
-                    d.cur.vy[j], d.cur.vz[j], vix, viy, viz, p_i, f);            // :86-89
+    const float4 rv = d.cur.rv[j];
+    pair_force_vals(d, pix - d.cur.x[j], piy - d.cur.y[j], piz - d.cur.z[j], rv.x, rv.y, rv.z, rv.w, vix, viy,
+                    viz, p_i, f);                                                // :86-89
 }
 
 // VelPos.compute:100-157: scaling, wall force, NaN guard, integrate, clamp, store.
@@ -129,7 +130,8 @@ __device__ __forceinline__ void integrate_store(const Dev &d, uint32_t s, float 
     d.nxt.x[s] = clamp01(pix + d.dt * vox);                                      // :153-154
     d.nxt.y[s] = clamp01(piy + d.dt * voy);
     d.nxt.z[s] = clamp01(piz + d.dt * voz);
-    d.nxt.vx[s] = vox; d.nxt.vy[s] = voy; d.nxt.vz[s] = voz; d.nxt.vw[s] = vow;  // :156-157
+    d.nxt.rv[s] = make_float4(rho_i, vox, voy, voz);                             // :156 (+ rho rides along)
+    d.nxt.vw[s] = vow;
     if (is_wild(vox) || is_wild(voy) || is_wild(voz)) d.counters[kCntWildV0 + (d.wild_v_cur ^ 1)] = 1ull;
 }
 
