@@ -105,6 +105,7 @@ typedef struct SphStats {
                                     the last sweep (moved > 1 cell, out of grid, tile overflow)  */
     uint64_t nan_resets;         /* NaN-guard hits (VelPos.compute:143-147) since create         */
     uint64_t candidates_density; /* listed candidates visited by the last density pass (P-bar*N) */
+    uint64_t halo_violations;    /* slab mode: owned targets that drifted beyond the ghost planes  */
 } SphStats;
 
 typedef struct SphContext SphContext;
@@ -149,6 +150,49 @@ int sph_synchronize(SphContext *ctx);
 
 /* Run on a caller-owned hipStream_t (e.g. torch's current stream) instead of the context's own. */
 int sph_set_stream(SphContext *ctx, void *hip_stream);
+
+/*
+ * ---- z-slab domain decomposition: one process per GPU (new work; the reference is single-GPU) ----
+ * A slab context holds the particles whose BUCKET ROW (Bucket.compute:26-29) lies in the grid planes
+ * cz in [z_lo, z_hi) plus "ghost" copies of halo_w planes on either side.  The host side (Python,
+ * sphfluidsimulation_amd/distributed.py) sequences one frame and moves the buffers between ranks
+ * with torch.distributed (RCCL over xGMI): nothing below communicates by itself.
+ *
+ *   begin_frame -> [exchange migrants] -> append(owned) -> export_ghosts -> [exchange ghosts]
+ *   -> append(ghost) -> sph_bucket_generation -> sph_density_calculation
+ *   -> pack_update(RHO) -> [exchange] -> unpack_update(RHO)
+ *   -> substeps x { sph_update_velocity_and_position ; pack_update(POSVEL) -> [exchange] -> unpack }
+ *
+ * send / recv arguments are DEVICE pointers owned by the caller (e.g. torch tensors):
+ * particle records are 9 fp32 words (x y z rho vx vy vz vel.w id), RHO updates 1 word, POSVEL
+ * updates 7 words (x y z rho vx vy vz), in the sender's export order.
+ * SphParams.num_particles stays the GLOBAL particle count (mass and sentinel depend on it).
+ */
+#define SPH_SLAB_UPDATE_RHO 0
+#define SPH_SLAB_UPDATE_POSVEL 1
+#define SPH_SLAB_RECORD_WORDS 9
+#define SPH_SLAB_POSVEL_WORDS 7
+
+int sph_slab_create(const SphParams *params, uint32_t local_capacity, SphContext **out);
+int sph_slab_configure(SphContext *ctx, int z_lo, int z_hi, int halo_w, int has_left, int has_right);
+/* n owned particles of this rank with their global ids (host arrays); vel4 may be NULL. */
+int sph_slab_upload(SphContext *ctx, uint32_t n, const float *pos4, const float *vel4, const uint32_t *ids);
+/* Drops last frame's ghosts, keeps what is still binned in this slab, packs what left it.
+ * counts = {kept, to_left, to_right}.  Synchronises. */
+int sph_slab_begin_frame(SphContext *ctx, void *send_left, void *send_right, uint32_t cap_records, uint32_t counts[3]);
+/* Appends received particle records as owned (as_ghost = 0, after migration) or as ghosts (1). */
+int sph_slab_append(SphContext *ctx, const void *recv_left, uint32_t n_left, const void *recv_right, uint32_t n_right,
+                    int as_ghost);
+/* Packs the owned particles binned in the halo_w boundary planes of each face.
+ * counts = {to_left, to_right}.  Synchronises. */
+int sph_slab_export_ghosts(SphContext *ctx, void *send_left, void *send_right, uint32_t cap_records, uint32_t counts[2]);
+int sph_slab_pack_update(SphContext *ctx, int what, void *send_left, void *send_right);
+int sph_slab_unpack_update(SphContext *ctx, int what, const void *recv_left, const void *recv_right);
+/* out = {owned, ghosts_from_left, ghosts_from_right, exported_to_left, exported_to_right}. */
+int sph_slab_counts(SphContext *ctx, uint32_t out[5]);
+/* Owned particles in arbitrary order with their ids; pos.w is 1 before the first sub-step. */
+int sph_slab_download(SphContext *ctx, uint32_t cap, uint32_t *ids, float *pos4, float *vel4, float *rho,
+                      uint32_t *n_out);
 
 /* Never NULL; ctx may be NULL for errors raised before a context exists. */
 const char *sph_last_error(SphContext *ctx);

@@ -17,6 +17,10 @@ SPH_E_UNSUPPORTED = -5
 SPH_E_COMM = -6
 SPH_FLAG_PROFILE = 1
 SPH_FLAG_NO_TILING = 2
+SPH_SLAB_UPDATE_RHO = 0
+SPH_SLAB_UPDATE_POSVEL = 1
+SPH_SLAB_RECORD_WORDS = 9
+SPH_SLAB_POSVEL_WORDS = 7
 
 _ERR_NAMES = {
     SPH_E_INVALID_ARG: "SPH_E_INVALID_ARG", SPH_E_BAD_STATE: "SPH_E_BAD_STATE", SPH_E_OOM: "SPH_E_OOM",
@@ -82,6 +86,7 @@ class SphStats(C.Structure):
         ("queued_targets", C.c_uint32),
         ("nan_resets", C.c_uint64),
         ("candidates_density", C.c_uint64),
+        ("halo_violations", C.c_uint64),
     ]
 
     def as_dict(self):
@@ -109,6 +114,16 @@ SYMBOLS = {
     "sph_reset_stats": (C.c_int, [_CTX]),
     "sph_synchronize": (C.c_int, [_CTX]),
     "sph_set_stream": (C.c_int, [_CTX, C.c_void_p]),
+    "sph_slab_create": (C.c_int, [C.POINTER(SphParams), C.c_uint32, C.POINTER(_CTX)]),
+    "sph_slab_configure": (C.c_int, [_CTX, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "sph_slab_upload": (C.c_int, [_CTX, C.c_uint32, _FP, _FP, C.POINTER(C.c_uint32)]),
+    "sph_slab_begin_frame": (C.c_int, [_CTX, C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]),
+    "sph_slab_append": (C.c_int, [_CTX, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_int]),
+    "sph_slab_export_ghosts": (C.c_int, [_CTX, C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]),
+    "sph_slab_pack_update": (C.c_int, [_CTX, C.c_int, C.c_void_p, C.c_void_p]),
+    "sph_slab_unpack_update": (C.c_int, [_CTX, C.c_int, C.c_void_p, C.c_void_p]),
+    "sph_slab_counts": (C.c_int, [_CTX, C.POINTER(C.c_uint32)]),
+    "sph_slab_download": (C.c_int, [_CTX, C.c_uint32, C.POINTER(C.c_uint32), _FP, _FP, _FP, C.POINTER(C.c_uint32)]),
     "sph_last_error": (C.c_char_p, [_CTX]),
 }
 

@@ -3,6 +3,7 @@
 #include "../../include/sph_hip.h"
 #include "sph_internal.hpp"
 
+#include <limits.h>
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
@@ -42,6 +43,15 @@ struct SphContext {
     double ms[3] = {0, 0, 0};
     uint64_t launches[3] = {0, 0, 0};
     std::string last_error;
+    // z-slab (multi-GPU) mode
+    bool slab = false;
+    uint32_t capacity = 0;            // particles the device arrays can hold
+    int z_lo = 0, z_hi = 0, halo_w = 2, has_left = 0, has_right = 0;
+    uint32_t n_ghost[2] = {0, 0};     // ghosts appended this frame (from left, from right)
+    uint32_t n_export[2] = {0, 0};    // owned particles exported as ghosts this frame (to left, to right)
+    uint32_t *send_src[2] = {nullptr, nullptr};
+    uint32_t *slab_counters = nullptr;  // 4 words, see k_slab_classify
+    uint32_t *ids_dev = nullptr;
 };
 
 static int fail(SphContext *ctx, int code, const char *fmt, ...)
@@ -94,7 +104,7 @@ static void refresh_scalars(SphContext *c)
     const SphDerived &dv = c->derived;
     Dev &d = c->dev;
     const float PI = 3.14159265358979323846264338327950288f;  // Density.compute:5, VelPos.compute:6
-    d.count = dv.particle_count;
+    if (!c->slab) d.count = dv.particle_count;   // slab contexts hold a varying local subset
     d.sentinel_n = dv.num_particles;
     d.R = dv.bucket_resolution;
     d.num_cells = d.R * d.R * d.R;
@@ -116,6 +126,10 @@ static void refresh_scalars(SphContext *c)
     d.gy = p.gravity[1];
     d.gz = p.gravity[2];
     d.use_bricks = (p.flags & SPH_FLAG_NO_TILING) ? 0u : 1u;
+    if (!c->slab) {
+        d.zt_lo = INT_MIN;
+        d.zt_hi = INT_MAX;
+    }
 }
 
 static int validate(SphContext *ctx, const SphParams *p)
@@ -218,6 +232,7 @@ static int do_bucket_generation(SphContext *c)
     HIP_TRY(c, hipGetLastError());
     std::swap(c->dev.cur, c->dev.nxt);
     std::swap(c->dev.id, c->dev.id_nxt);
+    std::swap(c->dev.ghost, c->dev.ghost_nxt);
     c->grid_valid = true;
     c->frames++;
     return SPH_OK;
@@ -284,7 +299,7 @@ int sph_params_default(SphParams *p)
     return SPH_OK;
 }
 
-int sph_create(const SphParams *params, SphContext **out)
+static int create_common(const SphParams *params, uint32_t capacity, bool slab, SphContext **out)
 {
     if (!out) return fail(nullptr, SPH_E_INVALID_ARG, "out is NULL");
     *out = nullptr;
@@ -303,8 +318,11 @@ int sph_create(const SphParams *params, SphContext **out)
     c->params = *params;
     c->device = params->device_id;
     c->profile = (params->flags & SPH_FLAG_PROFILE) != 0;
+    c->slab = slab;
     derive(c->params, &c->derived);
     refresh_scalars(c);
+    c->capacity = slab ? capacity : c->dev.count;
+    if (slab) c->dev.count = 0;
 
     auto bail = [&](int code) {
         std::string msg = c->last_error;
@@ -323,7 +341,7 @@ int sph_create(const SphParams *params, SphContext **out)
     c->own_stream = true;
 
     Dev &d = c->dev;
-    const size_t n = d.count;
+    const size_t n = c->capacity;
     const size_t cells = (size_t)d.num_cells + 2;
     const size_t scan_blocks = (cells + 4095) / 4096 + 1;
 #define A(expr)                         \
@@ -343,6 +361,15 @@ int sph_create(const SphParams *params, SphContext **out)
     A(dalloc(c, &c->vel4_dev, n));
     A(dalloc(c, &c->rho_id_dev, n));
     A(dalloc(c, &c->pw0, n));
+    if (slab) {
+        A(dalloc(c, &d.ghost, n));
+        A(dalloc(c, &d.ghost_nxt, n));
+        A(dalloc(c, &d.slot_of_src, n));
+        A(dalloc(c, &c->send_src[0], n));
+        A(dalloc(c, &c->send_src[1], n));
+        A(dalloc(c, &c->slab_counters, (size_t)4));
+        A(dalloc(c, &c->ids_dev, n));
+    }
 #undef A
     if (hipMemsetAsync(d.counters, 0, sizeof(unsigned long long) * kCntCount, c->stream) != hipSuccess ||
         hipMemsetAsync(d.cell_count, 0, sizeof(uint32_t) * cells, c->stream) != hipSuccess ||
@@ -351,8 +378,20 @@ int sph_create(const SphParams *params, SphContext **out)
         fail(c, SPH_E_HIP, "device memset failed");
         return bail(SPH_E_HIP);
     }
+    if (slab && (hipMemset(d.ghost, 0, n) != hipSuccess || hipMemset(d.ghost_nxt, 0, n) != hipSuccess)) {
+        fail(c, SPH_E_HIP, "device memset failed");
+        return bail(SPH_E_HIP);
+    }
     *out = c;
     return SPH_OK;
+}
+
+int sph_create(const SphParams *params, SphContext **out) { return create_common(params, 0, false, out); }
+
+int sph_slab_create(const SphParams *params, uint32_t local_capacity, SphContext **out)
+{
+    if (local_capacity == 0) return fail(nullptr, SPH_E_INVALID_ARG, "local_capacity is 0");
+    return create_common(params, local_capacity, true, out);
 }
 
 int sph_destroy(SphContext *c)
@@ -371,6 +410,7 @@ int sph_destroy(SphContext *c)
 int sph_upload(SphContext *c, const float *pos4, const float *vel4)
 {
     if (!c) return fail(nullptr, SPH_E_INVALID_ARG, "ctx is NULL");
+    if (c->slab) return fail(c, SPH_E_BAD_STATE, "slab context: use sph_slab_upload");
     if (!pos4) return fail(c, SPH_E_INVALID_ARG, "pos4 is NULL");
     HIP_TRY(c, hipSetDevice(c->device));
     const size_t bytes = (size_t)c->dev.count * sizeof(float4);
@@ -391,6 +431,7 @@ int sph_upload(SphContext *c, const float *pos4, const float *vel4)
 int sph_download(SphContext *c, float *pos4, float *vel4, float *rho)
 {
     if (!c) return fail(nullptr, SPH_E_INVALID_ARG, "ctx is NULL");
+    if (c->slab) return fail(c, SPH_E_BAD_STATE, "slab context: use sph_slab_download");
     if (!c->uploaded) return fail(c, SPH_E_BAD_STATE, "sph_download before sph_upload");
     HIP_TRY(c, hipSetDevice(c->device));
     launch_download_merge(c->dev, c->pw0, c->substeps_since_upload, c->dt_last, pos4 ? c->pos4_dev : nullptr,
@@ -428,6 +469,7 @@ int sph_update_velocity_and_position(SphContext *c, float dt)
 int sph_step(SphContext *c, float delta_time)
 {
     if (!c) return fail(nullptr, SPH_E_INVALID_ARG, "ctx is NULL");
+    if (c->slab) return fail(c, SPH_E_BAD_STATE, "slab context: the host drives the passes and the halo exchange");
     HIP_TRY(c, hipSetDevice(c->device));
     int rc;
     if ((rc = do_bucket_generation(c)) != SPH_OK) return rc;            // :98
@@ -501,6 +543,7 @@ int sph_get_stats(SphContext *c, SphStats *out)
     out->overflowed_cells = (uint32_t)cnt[kCntOverflowCells];
     out->dropped_particles = (uint32_t)cnt[kCntDropped];
     out->queued_targets = (uint32_t)cnt[kCntQueue];
+    out->halo_violations = cnt[kCntHaloViolation];
     out->nan_resets = cnt[kCntNaN];
     out->candidates_density = cnt[kCntCandidates];
     return SPH_OK;
@@ -535,6 +578,181 @@ const char *sph_last_error(SphContext *c)
 {
     if (c) return c->last_error.c_str();
     return g_last_error.c_str();
+}
+
+
+// ---- z-slab (multi-GPU) entry points: see include/sph_hip.h ----------------------------------------
+
+#define SLAB_CHECK(c)                                                                   \
+    if (!c) return fail(nullptr, SPH_E_INVALID_ARG, "ctx is NULL");                     \
+    if (!c->slab) return fail(c, SPH_E_BAD_STATE, "not a slab context (sph_slab_create)"); \
+    HIP_TRY(c, hipSetDevice(c->device))
+
+int sph_slab_configure(SphContext *c, int z_lo, int z_hi, int halo_w, int has_left, int has_right)
+{
+    SLAB_CHECK(c);
+    const int R = (int)c->dev.R;
+    if (z_lo < 0 || z_hi > R || z_lo >= z_hi || halo_w < 2)
+        return fail(c, SPH_E_INVALID_ARG, "bad slab range [%d,%d) of %d planes or halo %d < 2", z_lo, z_hi, R, halo_w);
+    c->z_lo = z_lo;
+    c->z_hi = z_hi;
+    c->halo_w = halo_w;
+    c->has_left = has_left != 0;
+    c->has_right = has_right != 0;
+    // an owned target may sit halo_w-1 planes outside the slab and still find its 27 cells in the halo
+    c->dev.zt_lo = c->has_left ? z_lo - (halo_w - 1) : INT_MIN;
+    c->dev.zt_hi = c->has_right ? z_hi - 1 + (halo_w - 1) : INT_MAX;
+    return SPH_OK;
+}
+
+int sph_slab_upload(SphContext *c, uint32_t n, const float *pos4, const float *vel4, const uint32_t *ids)
+{
+    SLAB_CHECK(c);
+    if (n > c->capacity) return fail(c, SPH_E_INVALID_ARG, "%u particles exceed the local capacity %u", n, c->capacity);
+    if (n && (!pos4 || !ids)) return fail(c, SPH_E_INVALID_ARG, "pos4 / ids is NULL");
+    HIP_TRY(c, hipMemcpyAsync(c->pos4_dev, pos4, (size_t)n * sizeof(float4), hipMemcpyHostToDevice, c->stream));
+    if (vel4) HIP_TRY(c, hipMemcpyAsync(c->vel4_dev, vel4, (size_t)n * sizeof(float4), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->ids_dev, ids, (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->dev.counters + kCntWildP, 0, sizeof(unsigned long long) * 3, c->stream));
+    c->dev.wild_v_cur = 0;
+    c->dev.force_slow = 0;
+    c->dev.count = n;
+    c->dev.n_owned = n;
+    launch_slab_upload(c->dev, n, c->pos4_dev, vel4 ? c->vel4_dev : nullptr, c->ids_dev, c->stream);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->uploaded = true;
+    c->grid_valid = false;
+    c->substeps_since_upload = 0;
+    c->n_ghost[0] = c->n_ghost[1] = c->n_export[0] = c->n_export[1] = 0;
+    return SPH_OK;
+}
+
+int sph_slab_begin_frame(SphContext *c, void *send_left, void *send_right, uint32_t cap_records, uint32_t counts[3])
+{
+    SLAB_CHECK(c);
+    if (!c->uploaded) return fail(c, SPH_E_BAD_STATE, "sph_slab_begin_frame before sph_slab_upload");
+    if (!counts) return fail(c, SPH_E_INVALID_ARG, "counts is NULL");
+    HIP_TRY(c, hipMemsetAsync(c->slab_counters, 0, 4 * sizeof(uint32_t), c->stream));
+    launch_slab_classify(c->dev, c->z_lo, c->z_hi, c->has_left, c->has_right, (float *)send_left, (float *)send_right,
+                         cap_records, c->slab_counters, c->stream);
+    HIP_TRY(c, hipGetLastError());
+    uint32_t h[4];
+    HIP_TRY(c, hipMemcpyAsync(h, c->slab_counters, sizeof h, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (h[1] > cap_records || h[2] > cap_records)
+        return fail(c, SPH_E_INVALID_ARG, "migration buffers too small: %u / %u records, capacity %u", h[1], h[2], cap_records);
+    std::swap(c->dev.cur, c->dev.nxt);
+    std::swap(c->dev.id, c->dev.id_nxt);
+    c->dev.count = h[0];
+    c->dev.n_owned = h[0];
+    c->grid_valid = false;
+    c->n_ghost[0] = c->n_ghost[1] = c->n_export[0] = c->n_export[1] = 0;
+    counts[0] = h[0];
+    counts[1] = h[1];
+    counts[2] = h[2];
+    return SPH_OK;
+}
+
+int sph_slab_append(SphContext *c, const void *recv_left, uint32_t n_left, const void *recv_right, uint32_t n_right,
+                    int as_ghost)
+{
+    SLAB_CHECK(c);
+    if ((uint64_t)c->dev.count + n_left + n_right > c->capacity)
+        return fail(c, SPH_E_OOM, "slab overflow: %u + %u + %u particles exceed the local capacity %u", c->dev.count,
+                    n_left, n_right, c->capacity);
+    if (!as_ghost && c->dev.count != c->dev.n_owned)
+        return fail(c, SPH_E_BAD_STATE, "owned particles must be appended before ghosts");
+    launch_slab_append(c->dev, (const float *)recv_left, n_left, c->dev.count, c->stream);
+    launch_slab_append(c->dev, (const float *)recv_right, n_right, c->dev.count + n_left, c->stream);
+    HIP_TRY(c, hipGetLastError());
+    c->dev.count += n_left + n_right;
+    if (as_ghost) {
+        c->n_ghost[0] = n_left;
+        c->n_ghost[1] = n_right;
+    } else {
+        c->dev.n_owned = c->dev.count;
+    }
+    return SPH_OK;
+}
+
+int sph_slab_export_ghosts(SphContext *c, void *send_left, void *send_right, uint32_t cap_records, uint32_t counts[2])
+{
+    SLAB_CHECK(c);
+    if (!counts) return fail(c, SPH_E_INVALID_ARG, "counts is NULL");
+    if (c->dev.count != c->dev.n_owned) return fail(c, SPH_E_BAD_STATE, "export ghosts before appending any");
+    HIP_TRY(c, hipMemsetAsync(c->slab_counters, 0, 4 * sizeof(uint32_t), c->stream));
+    const uint32_t cap = cap_records < c->capacity ? cap_records : c->capacity;
+    launch_slab_export(c->dev, c->z_lo, c->z_hi, c->halo_w, c->has_left, c->has_right, (float *)send_left,
+                       (float *)send_right, c->send_src[0], c->send_src[1], cap, c->slab_counters, c->stream);
+    HIP_TRY(c, hipGetLastError());
+    uint32_t h[4];
+    HIP_TRY(c, hipMemcpyAsync(h, c->slab_counters, sizeof h, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (h[1] > cap || h[2] > cap)
+        return fail(c, SPH_E_INVALID_ARG, "ghost buffers too small: %u / %u records, capacity %u", h[1], h[2], cap);
+    c->n_export[0] = counts[0] = h[1];
+    c->n_export[1] = counts[1] = h[2];
+    return SPH_OK;
+}
+
+int sph_slab_pack_update(SphContext *c, int what, void *send_left, void *send_right)
+{
+    SLAB_CHECK(c);
+    if (!c->grid_valid) return fail(c, SPH_E_BAD_STATE, "ghost update before BucketGeneration");
+    if (what != SPH_SLAB_UPDATE_RHO && what != SPH_SLAB_UPDATE_POSVEL) return fail(c, SPH_E_INVALID_ARG, "bad update kind");
+    launch_slab_pack_update(c->dev, c->send_src[0], c->n_export[0], what, (float *)send_left, c->stream);
+    launch_slab_pack_update(c->dev, c->send_src[1], c->n_export[1], what, (float *)send_right, c->stream);
+    HIP_TRY(c, hipGetLastError());
+    return SPH_OK;
+}
+
+int sph_slab_unpack_update(SphContext *c, int what, const void *recv_left, const void *recv_right)
+{
+    SLAB_CHECK(c);
+    if (!c->grid_valid) return fail(c, SPH_E_BAD_STATE, "ghost update before BucketGeneration");
+    if (what != SPH_SLAB_UPDATE_RHO && what != SPH_SLAB_UPDATE_POSVEL) return fail(c, SPH_E_INVALID_ARG, "bad update kind");
+    launch_slab_unpack_update(c->dev, c->dev.n_owned, c->n_ghost[0], what, (const float *)recv_left, c->stream);
+    launch_slab_unpack_update(c->dev, c->dev.n_owned + c->n_ghost[0], c->n_ghost[1], what, (const float *)recv_right,
+                              c->stream);
+    HIP_TRY(c, hipGetLastError());
+    return SPH_OK;
+}
+
+int sph_slab_counts(SphContext *c, uint32_t out[5])
+{
+    SLAB_CHECK(c);
+    if (!out) return fail(c, SPH_E_INVALID_ARG, "out is NULL");
+    out[0] = c->dev.n_owned;
+    out[1] = c->n_ghost[0];
+    out[2] = c->n_ghost[1];
+    out[3] = c->n_export[0];
+    out[4] = c->n_export[1];
+    return SPH_OK;
+}
+
+int sph_slab_download(SphContext *c, uint32_t cap, uint32_t *ids, float *pos4, float *vel4, float *rho, uint32_t *n_out)
+{
+    SLAB_CHECK(c);
+    if (!ids || !pos4 || !vel4 || !rho || !n_out) return fail(c, SPH_E_INVALID_ARG, "NULL argument");
+    if (!c->grid_valid) {   // before the first build: owned particles are the first n_owned entries, no ghosts
+        HIP_TRY(c, hipMemsetAsync(c->dev.ghost, 0, c->capacity, c->stream));
+    }
+    HIP_TRY(c, hipMemsetAsync(c->slab_counters, 0, 4 * sizeof(uint32_t), c->stream));
+    launch_slab_download(c->dev, c->substeps_since_upload, c->dt_last, c->slab_counters, c->ids_dev, c->pos4_dev,
+                         c->vel4_dev, c->rho_id_dev, c->stream);
+    HIP_TRY(c, hipGetLastError());
+    uint32_t n = 0;
+    HIP_TRY(c, hipMemcpyAsync(&n, c->slab_counters, sizeof n, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (n > cap) return fail(c, SPH_E_INVALID_ARG, "download arrays hold %u particles, %u owned", cap, n);
+    HIP_TRY(c, hipMemcpyAsync(ids, c->ids_dev, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(pos4, c->pos4_dev, (size_t)n * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(vel4, c->vel4_dev, (size_t)n * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(rho, c->rho_id_dev, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    *n_out = n;
+    return SPH_OK;
 }
 
 }  // extern "C"

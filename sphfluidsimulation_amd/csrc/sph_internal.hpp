@@ -43,6 +43,12 @@ struct Dev {
     uint2 *order;          // [count] (particle id, source slot) in new slot order
     uint32_t *block_sums;  // scan scratch
     uint32_t *queue;       // [count] target slots handed from the brick kernels to the generic kernels
+    // z-slab (multi-GPU) mode only; all nullptr / neutral otherwise
+    uint8_t *ghost;        // by slot: 1 = copy of a neighbour rank's particle (candidate only, never a target)
+    uint8_t *ghost_nxt;    // written by the reorder
+    uint32_t *slot_of_src; // inverse of the reorder permutation: pre-build index -> slot
+    uint32_t n_owned;      // pre-build indices [0, n_owned) are owned, [n_owned, count) are ghosts
+    int zt_lo, zt_hi;      // current-cell z range an owned target may reach without leaving the halo
     unsigned long long *counters;  // device statistics, see Counter
 };
 
@@ -56,6 +62,7 @@ enum Counter : int {
     kCntWildV0,         // some velocity component is >= 1e15, inf or NaN (two slots, ping-pong)
     kCntWildV1,
     kCntQueue,          // length of `queue` for the pass in flight
+    kCntHaloViolation,  // slab mode: owned targets whose 27 cells were not all covered by the halo
     kCntCount
 };
 
@@ -75,6 +82,18 @@ __device__ __forceinline__ uint32_t hlsl_uint(float f)
 }
 __device__ __forceinline__ float clamp01(float x) { return fminf(fmaxf(x, 0.0f), 1.0f); }
 
+// Bucket row of a particle, Bucket.compute:26-29: float3 idx_3d = int3(pos * (R-1)); the linear index
+// is evaluated in float (float3 component * uint) and converted to uint, then *= 32 in uint.
+// Returns num_cells ("limbo") when the row lies outside the bucket buffer.
+__device__ __forceinline__ uint32_t bucket_key(const Dev &d, float x, float y, float z)
+{
+    const float ix = (float)hlsl_int(x * d.Rm1), iy = (float)hlsl_int(y * d.Rm1), iz = (float)hlsl_int(z * d.Rm1);
+    uint32_t index = hlsl_uint((ix + iy * d.Rf) + iz * d.Rf * d.Rf);
+    index *= kMaxPerVoxel;
+    const unsigned long long len = (unsigned long long)d.num_cells * kMaxPerVoxel;
+    return (unsigned long long)index < len ? index / kMaxPerVoxel : d.num_cells;
+}
+
 // Cell coordinate of a position component: float3 idx_3d = int3(pos * (R-1))
 // (Bucket.compute:27, Density.compute:39, VelPos.compute:58).  Returned clamped to [-2, R+1]:
 // every coordinate outside that range behaves the same in the 27-cell sweep (all three
@@ -92,5 +111,19 @@ void launch_download_merge(const Dev &d, const float *pw0, int substeps_done, fl
 void launch_grid_build(const Dev &d, hipStream_t s);  // keys, histogram, scan, scatter, id-sort, reorder: cur -> nxt
 void launch_density(const Dev &d, hipStream_t s);     // sph_kernels_brick.hip (tiled) + queue
 void launch_velpos(const Dev &d, hipStream_t s);      // cur -> nxt
+
+
+// z-slab mode (sph_kernels_slab.hip)
+void launch_slab_upload(const Dev &d, uint32_t n, const float4 *pos4, const float4 *vel4, const uint32_t *ids, hipStream_t s);
+void launch_slab_classify(const Dev &d, int z_lo, int z_hi, int has_left, int has_right, float *send_l, float *send_r,
+                          uint32_t cap_records, uint32_t *counters, hipStream_t s);
+void launch_slab_append(const Dev &d, const float *recv, uint32_t n, uint32_t at, hipStream_t s);
+void launch_slab_export(const Dev &d, int z_lo, int z_hi, int halo_w, int has_left, int has_right, float *send_l,
+                        float *send_r, uint32_t *src_l, uint32_t *src_r, uint32_t cap_records, uint32_t *counters,
+                        hipStream_t s);
+void launch_slab_pack_update(const Dev &d, const uint32_t *send_src, uint32_t n, int what, float *out, hipStream_t s);
+void launch_slab_unpack_update(const Dev &d, uint32_t src0, uint32_t n, int what, const float *in, hipStream_t s);
+void launch_slab_download(const Dev &d, int substeps_done, float dt_last, uint32_t *counter, uint32_t *ids,
+                          float4 *pos4, float4 *vel4, float *rho, hipStream_t s);
 
 }  // namespace sph

@@ -272,6 +272,7 @@ __global__ void __launch_bounds__(T) k_density_brick(Dev d, int nbx, int nby)
         const uint32_t s = target_slot(s_row_start, s_row_pref, t);
         const float pix = d.cur.x[s], piy = d.cur.y[s], piz = d.cur.z[s];        // :38
         const int ix = cell_coord(pix, d.Rm1, R), iy = cell_coord(piy, d.Rm1, R), iz = cell_coord(piz, d.Rm1, R);
+        if (d.ghost && d.ghost[s]) continue;   // ghosts are candidates only
         if (!(axis_ok(ix, hx0, HB::HX, R) && axis_ok(iy, hy0, HB::HY, R) && axis_ok(iz, hz0, HB::HZ, R))) {
             enqueue(d, s);
             continue;
@@ -328,8 +329,10 @@ __global__ void __launch_bounds__(T) k_velpos_brick(Dev d, int nbx, int nby)
         const float pix = d.cur.x[s], piy = d.cur.y[s], piz = d.cur.z[s];        // :57
         const int ix = cell_coord(pix, d.Rm1, R), iy = cell_coord(piy, d.Rm1, R), iz = cell_coord(piz, d.Rm1, R);
         const bool inside = axis_ok(ix, hx0, HB::HX, R) && axis_ok(iy, hy0, HB::HY, R) && axis_ok(iz, hz0, HB::HZ, R);
+        if (d.ghost && d.ghost[s]) live = false;                                  // candidates only
         if (live && !inside) enqueue(d, s);
         live = live && inside;                 // dead lanes keep voting but look nothing up
+        if (live && (iz < d.zt_lo || iz > d.zt_hi)) atomicAdd(&d.counters[kCntHaloViolation], 1ull);
         const float4 rvi = d.cur.rv[s];
         const float rho_i = rvi.x;                                               // :60
         const float p_i = d.gas_const * (rho_i - d.rest_density);                // :61

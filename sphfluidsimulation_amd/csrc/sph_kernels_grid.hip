@@ -60,15 +60,7 @@ __global__ void __launch_bounds__(kBlock) k_cell_key_hist(Dev d)
 {
     const uint32_t p = blockIdx.x * kBlock + threadIdx.x;
     if (p >= d.count) return;
-    // :27 float3 idx_3d = int3(pos * (R-1))
-    const float ix = (float)hlsl_int(d.cur.x[p] * d.Rm1);
-    const float iy = (float)hlsl_int(d.cur.y[p] * d.Rm1);
-    const float iz = (float)hlsl_int(d.cur.z[p] * d.Rm1);
-    // :28 evaluated in float, then converted to uint; :29 index *= 32 in uint
-    uint32_t index = hlsl_uint((ix + iy * d.Rf) + iz * d.Rf * d.Rf);
-    index *= kMaxPerVoxel;
-    const unsigned long long len = (unsigned long long)d.num_cells * kMaxPerVoxel;
-    const uint32_t key = (unsigned long long)index < len ? index / kMaxPerVoxel : d.num_cells;
+    const uint32_t key = bucket_key(d, d.cur.x[p], d.cur.y[p], d.cur.z[p]);   // :26-29
     d.key[p] = key;
     atomicAdd(&d.cell_count[key], 1u);
 }
@@ -229,11 +221,15 @@ __global__ void __launch_bounds__(kBlock) k_reorder(Dev d)
     d.nxt.rv[s] = d.cur.rv[src];                       // the density texture persists by id
     d.nxt.vw[s] = d.cur.vw[src];
     d.id_nxt[s] = o.x;
+    if (d.slot_of_src) {                               // z-slab mode
+        d.slot_of_src[src] = s;
+        d.ghost_nxt[s] = src >= d.n_owned ? 1 : 0;
+    }
 }
 
 // ---- launchers ---------------------------------------------------------------------------------
 
-static inline uint32_t cdiv(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
+static inline uint32_t cdiv(uint32_t a, uint32_t b) { return a ? (a + b - 1) / b : 1u; }  // never an empty grid
 
 void launch_upload_split(const Dev &d, const float4 *pos4, const float4 *vel4, float *pw0, hipStream_t s)
 {

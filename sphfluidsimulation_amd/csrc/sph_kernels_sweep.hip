@@ -58,6 +58,8 @@ __device__ __forceinline__ void velpos_target(const Dev &d, uint32_t s, bool liv
     const float rho_i = rvi.x;                                                   // :60
     const float p_i = d.gas_const * (rho_i - d.rest_density);                    // :61
     const float vix = rvi.y, viy = rvi.z, viz = rvi.w, viw = d.cur.vw[s];        // :62
+    if (d.ghost && d.ghost[s]) live = false;             // ghosts are candidates only (their owner integrates them)
+    if (live && (iz < d.zt_lo || iz > d.zt_hi)) atomicAdd(&d.counters[kCntHaloViolation], 1ull);
 
     Force f{0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};                                 // :64-65
 
@@ -115,7 +117,7 @@ __global__ void __launch_bounds__(kBlock) k_density_exact(Dev d)
 {
     const uint32_t s = blockIdx.x * kBlock + threadIdx.x;
     unsigned long long v = 0;
-    if (s < d.count) v = density_target(d, s);
+    if (s < d.count && !(d.ghost && d.ghost[s])) v = density_target(d, s);
     v = wave_sum_u64(v);
     if ((threadIdx.x & (kWave - 1)) == 0 && v) atomicAdd(&d.counters[kCntCandidates], v);
 }
@@ -138,7 +140,7 @@ __global__ void __launch_bounds__(kBlock) k_density_queue(Dev d)
     unsigned long long v = 0;
     for (uint32_t q0 = blockIdx.x * kBlock; q0 < qlen; q0 += gridDim.x * kBlock) {
         const uint32_t q = q0 + threadIdx.x;
-        if (q < qlen) v += density_target(d, d.queue[q]);
+        if (q < qlen && !(d.ghost && d.ghost[d.queue[q]])) v += density_target(d, d.queue[q]);
     }
     v = wave_sum_u64(v);
     if ((threadIdx.x & (kWave - 1)) == 0 && v) atomicAdd(&d.counters[kCntCandidates], v);
@@ -155,7 +157,7 @@ __global__ void __launch_bounds__(kBlock) k_velpos_queue(Dev d)
     }
 }
 
-static inline uint32_t cdiv(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
+static inline uint32_t cdiv(uint32_t a, uint32_t b) { return a ? (a + b - 1) / b : 1u; }  // never an empty grid
 
 void launch_density_all(const Dev &d, hipStream_t s)
 {
