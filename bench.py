@@ -127,7 +127,7 @@ def main():
         "config": {"workload": workload, "particles": n, "bucket_resolution": R, "substeps": 5,
                    "mode": "exact_order"},
         "roofline": {
-            "bound": "hbm", "kernel": "k_velpos_exact", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "bound": "hbm", "kernel": "k_velpos_brick", "achieved": achieved, "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
             "kernel_ms": vel_ms, "launches": st["launches_velpos"],
             "step_hbm_frac": value * BYTES_PER_STEP / (HBM_PEAK_GBS * 1e9),
