@@ -66,6 +66,23 @@ def cpu_baseline(n, R, fill, pos0, vel0, dt_frame):
                        f"{dt:.2f} s wall, OpenMP {threads} threads, gcc -O2 -ffp-contract=off"), out
 
 
+def pmc_traffic(kernel_substr):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC run
+    (profiles/*_hbm_traffic_pmc.csv: FETCH_SIZE and WRITE_SIZE in separate passes, KiB).  FETCH_SIZE is
+    doubled as MI355X_MICROARCH.md prescribes for wide streaming reads (calibrated on k_upload_split in
+    profiles/README.md), so this is an upper bound for the 4-byte-per-lane part of the kernel's reads."""
+    import csv
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic_pmc.csv")))
+    if not files:
+        return None, None
+    for row in csv.DictReader(open(files[-1])):
+        if kernel_substr in row["kernel"]:
+            return (2.0 * float(row["avg_FETCH_SIZE_raw"]) + float(row["avg_WRITE_SIZE_raw"])) * 1024.0, \
+                os.path.relpath(files[-1], ROOT) + " (16 777 216 particles)"
+    return None, None
+
+
 def main():
     a = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -114,12 +131,19 @@ def main():
     elapsed = time.perf_counter() - t0
 
     st = sim.stats()
+    # boundary cost when the caller hands over HOST arrays every frame (never part of `value`)
+    t1 = time.perf_counter()
+    sim.upload(frame1[0], frame1[1])
+    t2 = time.perf_counter()
+    sim.download()
+    t3 = time.perf_counter()
     ms_per_step = elapsed * 1e3 / a.steps
     value = n * a.steps / elapsed
     pbar = st["candidates_density"] / n
     vel_ms = st["ms_velpos"] / max(st["launches_velpos"], 1)
     achieved = BYTES_PER_SUBSTEP * n / (vel_ms * 1e-3) / 1e9 if vel_ms > 0 else 0.0
     valu_tflops = value * pbar * (FLOPS_DENSITY + FLOPS_FORCE * 5) / 1e12
+    traffic, traffic_src = pmc_traffic("k_velpos_brick") if n == 16777216 else (None, None)
     out = {
         "metric": "particle-steps/s", "value": value, "unit": "particle-steps/s", "n_gpus": 1,
         "steps": a.steps, "warmup": warm, "ms_per_step": ms_per_step, "higher_is_better": True,
@@ -128,7 +152,8 @@ def main():
                    "mode": "exact_order"},
         "roofline": {
             "bound": "hbm", "kernel": "k_velpos_brick", "achieved": achieved, "peak": HBM_PEAK_GBS,
-            "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+            "algorithmic_bytes_per_launch": BYTES_PER_SUBSTEP * n,
             "kernel_ms": vel_ms, "launches": st["launches_velpos"],
             "step_hbm_frac": value * BYTES_PER_STEP / (HBM_PEAK_GBS * 1e9),
             "valu_frac": valu_tflops / VALU_PEAK_TFLOPS,
@@ -138,6 +163,8 @@ def main():
                       "density": st["ms_density"] / max(st["launches_density"], 1),
                       "velpos": vel_ms},
         "particle_substeps_per_s": value * 5,
+        "host_boundary": {"upload_ms": (t2 - t1) * 1e3, "download_ms": (t3 - t2) * 1e3,
+                          "pcie_inclusive_particle_steps_per_s": n / (elapsed / a.steps + (t3 - t1))},
         "max_cell_occupancy": st["max_cell_occupancy"], "nan_resets": st["nan_resets"],
         "queued_targets_last_sweep": st["queued_targets"],
     }

@@ -1,0 +1,112 @@
+// C++ host-side mirror of the reference driver Assets/Scripts/SphFluidSimulation.cs over the C ABI of
+// include/sph_hip.h (the reference's own toolchain, Unity C#, is not available in the build image, so
+// the host side above the ABI is C++ where the reference is compiled code; the C# binding a Unity
+// maintainer would add is in INTEGRATION.md and integration/unity/).
+// Same public field names (inspector fields :35-45) and method names (Start :82, Update :96,
+// OnDestroy :110, BucketGeneration :203, DensityCalculation :223, UpdateVelocityAndPosition :243).
+#pragma once
+
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "sph_hip.h"
+
+class SphFluidSimulation {
+public:
+    // inspector fields, SphFluidSimulation.cs:35-45
+    int preset = 1;
+    int particleNumber = 1024;
+    int bucketResolution = 256;
+    float damFillRate = 0.5f;
+    float viscosity = 0.01f;
+    float restDensity = 1.5f;
+    float gasConstant = 150.0f;
+    float stiffnessCoefficient = 5000.0f;
+    float dampingCoefficient = 10.0f;
+    int deviceId = 0;
+
+    ~SphFluidSimulation() { OnDestroy(); }
+
+    // :82-94; the reference fills the position texture with InitParticles.compute, here the caller
+    // hands the float4 arrays (id = y*res + x).  velocities may be nullptr (ClearFloat4, :189).
+    void Start(const float *positions, const float *velocities)
+    {
+        SphParams p = params();
+        check(sph_create(&p, &ctx_));
+        SphDerived d;
+        check(sph_get_derived(ctx_, &d));
+        particleNumber = (int)d.num_particles;            // :84
+        _particleTextureResolution = (int)d.particle_resolution;  // :85
+        _effectiveRadius = d.effective_radius;            // :159
+        _particleMass = d.particle_mass;                  // :176
+        count_ = d.particle_count;
+        check(sph_upload(ctx_, positions, velocities));
+    }
+
+    // :96-102 with Time.deltaTime = deltaTime
+    void Update(float deltaTime) { check(sph_step(ctx_, deltaTime)); }
+
+    // :110-120
+    void OnDestroy()
+    {
+        if (ctx_) sph_destroy(ctx_);
+        ctx_ = nullptr;
+    }
+
+    void BucketGeneration() { check(sph_bucket_generation(ctx_)); }                          // :203-221
+    void DensityCalculation() { check(sph_density_calculation(ctx_)); }                      // :223-241
+    void UpdateVelocityAndPosition(float dt) { check(sph_update_velocity_and_position(ctx_, dt)); }  // :243-269
+
+    // read-back of the Read textures (the reference never reads back; a drop-in must)
+    void Download(std::vector<float> &pos4, std::vector<float> &vel4, std::vector<float> &rho)
+    {
+        pos4.resize(4 * (size_t)count_);
+        vel4.resize(4 * (size_t)count_);
+        rho.resize(count_);
+        check(sph_download(ctx_, pos4.data(), vel4.data(), rho.data()));
+    }
+
+    // push changed inspector scalars mid-run
+    void ApplyParameters()
+    {
+        SphParams p = params();
+        check(sph_set_params(ctx_, &p));
+    }
+
+    SphStats Stats()
+    {
+        SphStats s;
+        check(sph_get_stats(ctx_, &s));
+        return s;
+    }
+
+    unsigned count() const { return count_; }
+    int _particleTextureResolution = 0;
+    float _effectiveRadius = 0.0f, _particleMass = 0.0f;
+
+private:
+    SphContext *ctx_ = nullptr;
+    unsigned count_ = 0;
+
+    SphParams params() const
+    {
+        SphParams p;
+        sph_params_default(&p);
+        p.num_particles = (uint32_t)particleNumber;
+        p.bucket_resolution = (uint32_t)bucketResolution;
+        p.dam_fill_rate = damFillRate;
+        p.viscosity = viscosity;
+        p.rest_density = restDensity;
+        p.gas_constant = gasConstant;
+        p.stiffness_coeff = stiffnessCoefficient;
+        p.damping_coeff = dampingCoefficient;
+        p.device_id = deviceId;
+        return p;
+    }
+
+    void check(int rc)
+    {
+        if (rc != SPH_OK) throw std::runtime_error(std::string("libsph_hip: ") + sph_last_error(ctx_));
+    }
+};

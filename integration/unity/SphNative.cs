@@ -1,0 +1,77 @@
+// P/Invoke binding of include/sph_hip.h for Unity (Linux player / editor, libsph_hip.so on the
+// plugin path, e.g. Assets/Plugins/x86_64/).  Written against the header; it could NOT be compiled
+// in the build image (no Unity / dotnet / mono there) -- the same ABI is exercised from C++
+// (host/sph_host_demo.cpp) and Python ctypes (sphfluidsimulation_amd/_native.py).
+using System;
+using System.Runtime.InteropServices;
+
+public static class SphNative
+{
+    const string Lib = "sph_hip";
+
+    public const int SPH_OK = 0;
+    public const uint SPH_FLAG_PROFILE = 1u;
+
+    [StructLayout(LayoutKind.Sequential)]
+    public struct SphParams
+    {
+        public uint struct_size;        // = Marshal.SizeOf<SphParams>() (76)
+        public uint num_particles;      // particleNumber,        SphFluidSimulation.cs:36
+        public uint bucket_resolution;  // bucketResolution,      :37
+        public float dam_fill_rate;     // damFillRate,           :38
+        public float viscosity;         // viscosity,             :41
+        public float rest_density;      // restDensity,           :42
+        public float gas_constant;      // gasConstant,           :43
+        public float stiffness_coeff;   // stiffnessCoefficient,  :44
+        public float damping_coeff;     // dampingCoefficient,    :45
+        public uint max_per_voxel;      // MaxParticlesPerVoxel,  :9
+        public uint substeps;           // 5,                     :101
+        public float dt_divisor;        // 25,                    :102
+        public float gravity_x, gravity_y, gravity_z;  // VelPos.compute:7
+        public uint precision;
+        public uint exact_order;
+        public int device_id;
+        public uint flags;
+    }
+
+    [StructLayout(LayoutKind.Sequential)]
+    public struct SphDerived
+    {
+        public uint num_particles, particle_resolution, particle_count, bucket_resolution;
+        public float particle_mass, effective_radius, effective_radius2, effective_radius6, effective_radius9;
+    }
+
+    [StructLayout(LayoutKind.Sequential)]
+    public struct SphStats
+    {
+        public ulong frames, substeps;
+        public double ms_grid, ms_density, ms_velpos;
+        public ulong launches_grid, launches_density, launches_velpos;
+        public uint max_cell_occupancy, overflowed_cells, dropped_particles, queued_targets;
+        public ulong nan_resets, candidates_density, halo_violations;
+    }
+
+    [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int sph_version();
+    [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int sph_params_default(out SphParams p);
+    [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int sph_create(ref SphParams p, out IntPtr ctx);
+    [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int sph_destroy(IntPtr ctx);
+    [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int sph_upload(IntPtr ctx, float[] pos4, float[] vel4);
+    [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int sph_download(IntPtr ctx, float[] pos4, float[] vel4, float[] rho);
+    [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int sph_step(IntPtr ctx, float deltaTime);
+    [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int sph_step_n(IntPtr ctx, float deltaTime, int frames);
+    [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int sph_bucket_generation(IntPtr ctx);
+    [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int sph_density_calculation(IntPtr ctx);
+    [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int sph_update_velocity_and_position(IntPtr ctx, float dt);
+    [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int sph_set_params(IntPtr ctx, ref SphParams p);
+    [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int sph_get_derived(IntPtr ctx, out SphDerived d);
+    [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int sph_get_stats(IntPtr ctx, out SphStats s);
+    [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int sph_reset_stats(IntPtr ctx);
+    [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int sph_synchronize(IntPtr ctx);
+    [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern IntPtr sph_last_error(IntPtr ctx);
+
+    public static void Check(int rc, IntPtr ctx)
+    {
+        if (rc != SPH_OK)
+            throw new InvalidOperationException("libsph_hip (" + rc + "): " + Marshal.PtrToStringAnsi(sph_last_error(ctx)));
+    }
+}

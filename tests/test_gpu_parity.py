@@ -280,3 +280,16 @@ def test_full_size_16m_density_pass_and_invariants(oracle):
     # gravity only acts on y and walls are symmetric in z for this set: bulk moved down
     assert vel[:, 1].mean() < 0
     sim.OnDestroy()
+
+
+def test_cpp_host_mirror_runs():
+    """host/sph_host_demo.cpp: the C++ mirror of the reference driver over the C ABI, no Python in the loop."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "host", "sph_host_demo")
+    if not os.path.exists(exe):
+        import __graft_entry__
+        __graft_entry__.build()
+    out = subprocess.run([exe, "262144", "47", "4"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "violations=0" in out.stdout and "nan_resets=0" in out.stdout
