@@ -36,14 +36,21 @@ namespace sph {
 #define SPH_DENSITY_T 256
 #endif
 #ifndef SPH_VELPOS_CAP
-#define SPH_VELPOS_CAP 4096
+#define SPH_VELPOS_CAP 3328
 #endif
 #ifndef SPH_DENSITY_CAP
-#define SPH_DENSITY_CAP 3072
+#define SPH_DENSITY_CAP 2048
 #endif
 #ifndef SPH_LCAP
-#define SPH_LCAP 24
+#define SPH_LCAP 32
 #endif
+#ifndef SPH_DENSITY_MINWAVES
+#define SPH_DENSITY_MINWAVES 5
+#endif
+#ifndef SPH_SCAN_UNROLL
+#define SPH_SCAN_UNROLL 4
+#endif
+constexpr int kU = SPH_SCAN_UNROLL;             // slots per trip of the neighbour scans
 constexpr int BX = 8, BY = SPH_BRICK_BY, BZ = 4;  // owned cells per brick
 constexpr int kRows = BY * BZ;
 
@@ -130,25 +137,23 @@ __device__ __forceinline__ int hcz(const BrickGeom g, int cx, int cy, int cz)
     return (cz - (g.z0 - H)) + HB::HZ * ((cy - (g.y0 - H)) + HB::HY * (cx - (g.x0 - H)));
 }
 
-// Common set-up: owned rows, halo cell table, staging of positions.  Returns the number of owned
-// particles (0: nothing to do or everything was queued).
-template <int H, int CAP, int T>
-__device__ __forceinline__ uint32_t brick_setup(const Dev &d, const BrickGeom g, bool force_queue, float *sx,
-                                                float *sy, float *sz, uint32_t *s_info, uint32_t *s_g0,
-                                                uint32_t *s_row_start, uint32_t *s_row_pref, uint32_t *s_scan)
+// Common set-up for the owned cells [g.x0, g.x0+nx) x BY x BZ: owned rows, halo cell table, staging of
+// positions.  Returns kEmpty (no owned particle), kReady (tile staged, *Tn owned particles) or
+// kOverflow (the listed particles of the halo box exceed the tile; rows are valid, nothing staged).
+enum { kEmpty = 0, kReady = 1, kOverflow = 2 };
+
+// Slot runs of the owned rows (y,z) of the cells [g.x0, g.x0+nx): fills s_row_start / s_row_pref and returns
+// the number of owned particles (every member of a cell is a target, also the ones beyond the 32-cap).
+__device__ __forceinline__ uint32_t brick_rows(const Dev &d, const BrickGeom g, int nx, uint32_t *s_row_start,
+                                               uint32_t *s_row_pref)
 {
-    using HB = Halo<H, T>;
     const uint32_t tid = threadIdx.x;
     const int R = (int)d.R;
-
-    if (blockIdx.x == 0)  // limbo particles belong to no brick
-        for (uint32_t t = d.cell_start[d.num_cells] + tid; t < d.count; t += T) enqueue(d, t);
-
     if (tid < kRows) {
         const int cy = g.y0 + (int)(tid % BY), cz = g.z0 + (int)(tid / BY);
         uint32_t st = 0, len = 0;
-        if (cy < R && cz < R) {
-            const int xb = g.x0 + BX - 1 < R - 1 ? g.x0 + BX - 1 : R - 1;
+        if (cy < R && cz < R && g.x0 < R) {
+            const int xb = g.x0 + nx - 1 < R - 1 ? g.x0 + nx - 1 : R - 1;
             const uint32_t row = (uint32_t)cy * d.R + (uint32_t)cz * d.R * d.R;
             st = d.cell_start[row + (uint32_t)g.x0];
             len = d.cell_start[row + (uint32_t)xb + 1u] - st;
@@ -162,8 +167,20 @@ __device__ __forceinline__ uint32_t brick_setup(const Dev &d, const BrickGeom g,
         for (int r = 0; r < kRows; r++) s_row_pref[r + 1] += s_row_pref[r];
     }
     __syncthreads();
-    const uint32_t Tn = s_row_pref[kRows];
-    if (Tn == 0) return 0;
+    return s_row_pref[kRows];
+}
+
+template <int H, int CAP, int T>
+__device__ __forceinline__ int brick_setup(const Dev &d, const BrickGeom g, int nx, float *sx, float *sy, float *sz,
+                                           uint32_t *s_info, uint32_t *s_g0, uint32_t *s_row_start,
+                                           uint32_t *s_row_pref, uint32_t *s_scan, uint32_t *Tn_out)
+{
+    using HB = Halo<H, T>;
+    const uint32_t tid = threadIdx.x;
+    const int R = (int)d.R;
+    const uint32_t Tn = brick_rows(d, g, nx, s_row_start, s_row_pref);
+    *Tn_out = Tn;
+    if (Tn == 0) return kEmpty;
 
     // A: bucket rows of the halo cells, threads x-fastest (coalesced cell_start reads)
     uint32_t cnt[HB::PER], g0[HB::PER];
@@ -177,7 +194,7 @@ __device__ __forceinline__ uint32_t brick_setup(const Dev &d, const BrickGeom g,
         if (a < HB::NH) {
             const int cx = g.x0 - H + a % HB::HX, cy = g.y0 - H + (a / HB::HX) % HB::HY,
                       cz = g.z0 - H + a / (HB::HX * HB::HY);
-            if (cx >= 0 && cy >= 0 && cz >= 0 && cx < R && cy < R && cz < R) {
+            if (a % HB::HX < nx + 2 * H && cx >= 0 && cy >= 0 && cz >= 0 && cx < R && cy < R && cz < R) {
                 const uint32_t key = (uint32_t)cx + (uint32_t)cy * d.R + (uint32_t)cz * d.R * d.R;
                 const uint32_t st = d.cell_start[key];
                 const uint32_t n = d.cell_start[key + 1] - st;
@@ -199,10 +216,7 @@ __device__ __forceinline__ uint32_t brick_setup(const Dev &d, const BrickGeom g,
     }
     uint32_t total;
     uint32_t run = brick_excl_scan<T>(sum, s_scan, &total);
-    if (force_queue || total > (uint32_t)CAP) {
-        for (uint32_t t = tid; t < Tn; t += T) enqueue(d, target_slot(s_row_start, s_row_pref, t));
-        return 0;
-    }
+    if (total > (uint32_t)CAP) return kOverflow;
 #pragma unroll
     for (int i = 0; i < HB::PER; i++) {
         const int b = (int)tid * HB::PER + i;
@@ -226,7 +240,44 @@ __device__ __forceinline__ uint32_t brick_setup(const Dev &d, const BrickGeom g,
         }
     }
     __syncthreads();
-    return Tn;
+    return kReady;
+}
+
+// Walks the brick's owned x-range: the whole brick if its halo fits the tile, otherwise halves
+// (down to 2 cells) so that crowded regions stay on the LDS path; what still does not fit goes to
+// the generic queue.  `body(sub_geom, nx, Tn)` sweeps one staged sub-brick.
+template <int H, int CAP, int T, typename Body>
+__device__ __forceinline__ void for_each_subbrick(const Dev &d, const BrickGeom g, bool force_queue, float *sx,
+                                                  float *sy, float *sz, uint32_t *s_info, uint32_t *s_g0,
+                                                  uint32_t *s_row_start, uint32_t *s_row_pref, uint32_t *s_scan,
+                                                  Body body)
+{
+    if (blockIdx.x == 0)  // limbo particles belong to no brick
+        for (uint32_t t = d.cell_start[d.num_cells] + threadIdx.x; t < d.count; t += T) enqueue(d, t);
+    int xa = g.x0, w = BX;
+    while (xa < g.x0 + BX) {                                   // block-uniform
+        __syncthreads();                                       // the previous sweep is done with the tile
+        const BrickGeom sg{xa, g.y0, g.z0};
+        uint32_t Tn = 0;
+        int rc = kOverflow;
+        if (force_queue) {
+            w = BX;                                            // rows only: the literal kernel takes the whole brick
+            Tn = brick_rows(d, sg, w, s_row_start, s_row_pref);
+            rc = Tn ? kOverflow : kEmpty;
+        } else {
+            rc = brick_setup<H, CAP, T>(d, sg, w, sx, sy, sz, s_info, s_g0, s_row_start, s_row_pref, s_scan, &Tn);
+            if (rc == kOverflow && w > 2) {
+                w >>= 1;                                       // retry the left half
+                continue;
+            }
+        }
+        if (rc == kOverflow)
+            for (uint32_t t = threadIdx.x; t < Tn; t += T) enqueue(d, target_slot(s_row_start, s_row_pref, t));
+        else if (rc == kReady)
+            body(sg, w, Tn);
+        xa += w;
+        while (w < BX && ((xa - g.x0) % (2 * w)) == 0) w <<= 1;  // try the widest aligned range again
+    }
 }
 
 // One (x_offset, y_offset) column of the 27-cell stencil: the in-grid cells (cx, cy, iz-1..iz+1)
@@ -254,26 +305,25 @@ __device__ __forceinline__ Run stencil_run(const BrickGeom g, const uint32_t *s_
 // ---- Density.compute:29-60 ---------------------------------------------------------------------
 
 template <int H, int CAP, int T>
-__global__ void __launch_bounds__(T) k_density_brick(Dev d, int nbx, int nby)
+__global__ void __launch_bounds__(T, SPH_DENSITY_MINWAVES) k_density_brick(Dev d, int nbx, int nby)
 {
     using HB = Halo<H, T>;
-    __shared__ float sx[CAP + 4], sy[CAP + 4], sz[CAP + 4];   // +4: the unrolled scan may read past a run
+    __shared__ float sx[CAP + kU], sy[CAP + kU], sz[CAP + kU];   // +kU: the unrolled scan may read past a run
     __shared__ uint32_t s_info[HB::NH], s_g0[HB::NH];
     __shared__ uint32_t s_row_start[kRows], s_row_pref[kRows + 1], s_scan[T / kWave + 1];
 
-    const BrickGeom g = brick_geom(nbx, nby);
-    const uint32_t Tn = brick_setup<H, CAP, T>(d, g, false, sx, sy, sz, s_info, s_g0, s_row_start, s_row_pref, s_scan);
-    if (Tn == 0) return;
-
+    const BrickGeom g0 = brick_geom(nbx, nby);
     const int R = (int)d.R;
-    const int hx0 = g.x0 - H, hy0 = g.y0 - H, hz0 = g.z0 - H;
     unsigned long long visited = 0;
+    for_each_subbrick<H, CAP, T>(d, g0, false, sx, sy, sz, s_info, s_g0, s_row_start, s_row_pref, s_scan,
+                                 [&](const BrickGeom g, int nx, uint32_t Tn) {
+    const int hx0 = g.x0 - H, hy0 = g.y0 - H, hz0 = g.z0 - H;
     for (uint32_t t = threadIdx.x; t < Tn; t += T) {
         const uint32_t s = target_slot(s_row_start, s_row_pref, t);
         const float pix = d.cur.x[s], piy = d.cur.y[s], piz = d.cur.z[s];        // :38
         const int ix = cell_coord(pix, d.Rm1, R), iy = cell_coord(piy, d.Rm1, R), iz = cell_coord(piz, d.Rm1, R);
         if (d.ghost && d.ghost[s]) continue;   // ghosts are candidates only
-        if (!(axis_ok(ix, hx0, HB::HX, R) && axis_ok(iy, hy0, HB::HY, R) && axis_ok(iz, hz0, HB::HZ, R))) {
+        if (!(axis_ok(ix, hx0, nx + 2 * H, R) && axis_ok(iy, hy0, HB::HY, R) && axis_ok(iz, hz0, HB::HZ, R))) {
             enqueue(d, s);
             continue;
         }
@@ -282,44 +332,44 @@ __global__ void __launch_bounds__(T) k_density_brick(Dev d, int nbx, int nby)
             for (int yo = -1; yo <= 1; yo++) {                                   // :43
                 const Run r = stencil_run<H>(g, s_info, ix + xo, iy + yo, iz, R); // :44-49, z_offset run
                 visited += r.cnt;
-                for (uint32_t p = 0; p < r.cnt; p += 4) {                        // :50-55, 4 slots per trip
-                    float w[4];
+                for (uint32_t p = 0; p < r.cnt; p += kU) {                       // :50-55, kU slots per trip
+                    float w[kU];
 #pragma unroll
-                    for (int u = 0; u < 4; u++) {
+                    for (int u = 0; u < kU; u++) {
                         const uint32_t idx = r.base + p + u;
                         w[u] = density_term(d, pix - sx[idx], piy - sy[idx], piz - sz[idx]);
                     }
 #pragma unroll
-                    for (int u = 0; u < 4; u++) rho += (p + u < r.cnt) ? w[u] : 0.0f;  // + 0.0f is exact
+                    for (int u = 0; u < kU; u++) rho += (p + u < r.cnt) ? w[u] : 0.0f;  // + 0.0f is exact
                 }
             }
         d.cur.rv[s].x = rho;                                                     // :59
         if (is_wild(d.gas_const * (rho - d.rest_density))) d.counters[kCntWildP] = 1ull;
     }
+                                 });
     visited = wave_sum_u64(visited);
     if ((threadIdx.x & (kWave - 1)) == 0 && visited) atomicAdd(&d.counters[kCntCandidates], visited);
 }
 
 // ---- VelPos.compute:46-158 ---------------------------------------------------------------------
 
+// two 512-thread bricks per CU (LDS-limited): 4 waves per SIMD, i.e. at most 128 VGPRs
 template <int H, int CAP, int LCAP, int T>
-__global__ void __launch_bounds__(T) k_velpos_brick(Dev d, int nbx, int nby)
+__global__ void __launch_bounds__(T, 2 * T / 256) k_velpos_brick(Dev d, int nbx, int nby)
 {
     constexpr int kT = T;
     using HB = Halo<H, T>;
-    __shared__ float sx[CAP + 4], sy[CAP + 4], sz[CAP + 4];
+    __shared__ float sx[CAP + kU], sy[CAP + kU], sz[CAP + kU];
     __shared__ uint32_t s_info[HB::NH], s_g0[HB::NH];
     __shared__ uint32_t s_row_start[kRows], s_row_pref[kRows + 1], s_scan[kT / kWave + 1];
     __shared__ uint32_t s_list32[(LCAP / 2) * kT];  // u16 entries, dword column = thread
     uint16_t *list = reinterpret_cast<uint16_t *>(s_list32);
 
-    const BrickGeom g = brick_geom(nbx, nby);
-    const uint32_t Tn = brick_setup<H, CAP, T>(d, g, launch_is_wild(d), sx, sy, sz, s_info, s_g0, s_row_start,
-                                           s_row_pref, s_scan);
-    if (Tn == 0) return;
-
+    const BrickGeom g0 = brick_geom(nbx, nby);
     const uint32_t tid = threadIdx.x;
     const int R = (int)d.R;
+    for_each_subbrick<H, CAP, T>(d, g0, launch_is_wild(d), sx, sy, sz, s_info, s_g0, s_row_start, s_row_pref, s_scan,
+                                 [&](const BrickGeom g, int nx, uint32_t Tn) {
     const int hx0 = g.x0 - H, hy0 = g.y0 - H, hz0 = g.z0 - H;
 
     for (uint32_t tb = 0; tb < Tn; tb += kT) {                                   // block-uniform
@@ -328,7 +378,7 @@ __global__ void __launch_bounds__(T) k_velpos_brick(Dev d, int nbx, int nby)
         const uint32_t s = target_slot(s_row_start, s_row_pref, live ? t : Tn - 1);
         const float pix = d.cur.x[s], piy = d.cur.y[s], piz = d.cur.z[s];        // :57
         const int ix = cell_coord(pix, d.Rm1, R), iy = cell_coord(piy, d.Rm1, R), iz = cell_coord(piz, d.Rm1, R);
-        const bool inside = axis_ok(ix, hx0, HB::HX, R) && axis_ok(iy, hy0, HB::HY, R) && axis_ok(iz, hz0, HB::HZ, R);
+        const bool inside = axis_ok(ix, hx0, nx + 2 * H, R) && axis_ok(iy, hy0, HB::HY, R) && axis_ok(iz, hz0, HB::HZ, R);
         if (d.ghost && d.ghost[s]) live = false;                                  // candidates only
         if (live && !inside) enqueue(d, s);
         live = live && inside;                 // dead lanes keep voting but look nothing up
@@ -396,21 +446,21 @@ __global__ void __launch_bounds__(T) k_velpos_brick(Dev d, int nbx, int nby)
             if (!live) r.cnt = 0;
             uint32_t p = 0;
             while (true) {
-                while (p < r.cnt && n + 4 <= (uint32_t)LCAP) {
-                    float r2[4];
+                while (p < r.cnt && n + kU <= (uint32_t)LCAP) {
+                    float r2[kU];
 #pragma unroll
-                    for (int u = 0; u < 4; u++) {
+                    for (int u = 0; u < kU; u++) {
                         const uint32_t idx = r.base + p + u;
                         const float rx = pix - sx[idx], ry = piy - sy[idx], rz = piz - sz[idx];
                         r2[u] = (rx * rx + ry * ry) + rz * rz;
                     }
 #pragma unroll
-                    for (int u = 0; u < 4; u++)
+                    for (int u = 0; u < kU; u++)
                         if (p + u < r.cnt && r2[u] < d.h2_up) {   // superset of |r| < h (VelPos.compute:37,43)
                             list[(((n >> 1) * kT + tid) << 1) + (n & 1u)] = (uint16_t)((c << 7) | (p + u));
                             n++;
                         }
-                    p += 4;
+                    p += kU;
                 }
                 if (!__any(p < r.cnt)) break;  // every lane finished this column
                 phase2(n);                     // some lane's list is nearly full: drain all lists
@@ -420,6 +470,7 @@ __global__ void __launch_bounds__(T) k_velpos_brick(Dev d, int nbx, int nby)
         phase2(n);
         if (live) integrate_store(d, s, pix, piy, piz, vix, viy, viz, viw, rho_i, f);  // :100-157
     }
+                                 });
 }
 
 // ---- launchers -----------------------------------------------------------------------------------

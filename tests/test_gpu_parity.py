@@ -117,6 +117,24 @@ def test_ten_frames_c1(oracle):
     sim.OnDestroy()
 
 
+def test_forty_frames_through_the_collapse(oracle):
+    """Longer horizon at C1: the dam collapses, cells crowd (tile splitting, 32-cap) and particles
+    cross bins inside a frame; bit-identity must survive all of it."""
+    n, R, fill = 262144, 47, 0.8
+    dt_frame = presets.bench_dt_frame(R)
+    pos0, vel0 = presets.dam_break(n, fill, seed=31)
+    sim = engine(n, R, fill).Start(pos0, vel0)
+    ora = oracle.OracleSimulation(oracle.derive(n, R, fill, **SCENE))
+    ora.upload(pos0, vel0)
+    for f in range(1, 41):
+        sim.Update(dt_frame)
+        ora.Update(dt_frame)
+        if f % 10 == 0:
+            for x, y, nm in zip(sim.download(), ora.download(), ("pos", "vel", "rho")):
+                assert_parity(x, y, f"C1 frame {f}: {nm}")
+    sim.OnDestroy()
+
+
 def test_staged_calls_equal_step():
     n, R = 4096, 13
     pos0, vel0 = presets.dam_break(n, 0.8, seed=2)
