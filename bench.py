@@ -44,6 +44,7 @@ def parse():
     ap.add_argument("--particles", type=int, default=16777216)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-slab", action="store_true", help="diagnostic: run the z-slab driver even with one rank")
     return ap.parse_args()
 
 
@@ -101,7 +102,7 @@ def main():
     dt_frame = presets.bench_dt_frame(R)
     workload = f"dam-break Preset1 lattice, {n} particles, R={R}, fill 0.8, scene parameters, dt_frame=0.7667h, seed {a.seed}"
 
-    if world > 1:
+    if world > 1 or a.force_slab:
         from sphfluidsimulation_amd import distributed as D
         result = D.bench_main(a, n, R, fill, dt_frame, rank, world, local_rank)
         if rank == 0:

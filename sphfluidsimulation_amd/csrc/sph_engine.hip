@@ -129,6 +129,8 @@ static void refresh_scalars(SphContext *c)
     if (!c->slab) {
         d.zt_lo = INT_MIN;
         d.zt_hi = INT_MAX;
+        d.zo_lo = 0;
+        d.zo_hi = (int)d.R;
     }
 }
 
@@ -602,6 +604,8 @@ int sph_slab_configure(SphContext *c, int z_lo, int z_hi, int halo_w, int has_le
     // an owned target may sit halo_w-1 planes outside the slab and still find its 27 cells in the halo
     c->dev.zt_lo = c->has_left ? z_lo - (halo_w - 1) : INT_MIN;
     c->dev.zt_hi = c->has_right ? z_hi - 1 + (halo_w - 1) : INT_MAX;
+    c->dev.zo_lo = z_lo;   // bricks made only of ghost planes have no targets and return at once
+    c->dev.zo_hi = z_hi;
     return SPH_OK;
 }
 

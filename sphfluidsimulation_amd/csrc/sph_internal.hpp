@@ -49,6 +49,7 @@ struct Dev {
     uint32_t *slot_of_src; // inverse of the reorder permutation: pre-build index -> slot
     uint32_t n_owned;      // pre-build indices [0, n_owned) are owned, [n_owned, count) are ghosts
     int zt_lo, zt_hi;      // current-cell z range an owned target may reach without leaving the halo
+    int zo_lo, zo_hi;      // grid planes whose particles are targets here (whole grid outside slab mode)
     unsigned long long *counters;  // device statistics, see Counter
 };
 

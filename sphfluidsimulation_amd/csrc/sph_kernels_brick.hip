@@ -152,7 +152,7 @@ __device__ __forceinline__ uint32_t brick_rows(const Dev &d, const BrickGeom g, 
     if (tid < kRows) {
         const int cy = g.y0 + (int)(tid % BY), cz = g.z0 + (int)(tid / BY);
         uint32_t st = 0, len = 0;
-        if (cy < R && cz < R && g.x0 < R) {
+        if (cy < R && cz < R && g.x0 < R && cz >= d.zo_lo && cz < d.zo_hi) {   // ghost planes hold no targets
             const int xb = g.x0 + nx - 1 < R - 1 ? g.x0 + nx - 1 : R - 1;
             const uint32_t row = (uint32_t)cy * d.R + (uint32_t)cz * d.R * d.R;
             st = d.cell_start[row + (uint32_t)g.x0];

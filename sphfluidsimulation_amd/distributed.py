@@ -324,6 +324,10 @@ def bench_main(a, n, R, fill, dt_frame, rank, world, local_rank):
     if os.environ.get("SPH_DIST_SINGLE_DEVICE") == "1":
         local_rank = 0
     torch.cuda.set_device(local_rank)
+    if not dist.is_initialized() and world == 1:      # --force-slab diagnostic without a launcher
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29577")
+        dist.init_process_group("gloo", rank=0, world_size=1)
     if not dist.is_initialized():
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
