@@ -1,0 +1,21 @@
+"""Diagnostic: per-brick phase durations of k_velpos_brick (build with SPH_HIPCC_EXTRA=-DSPH_STAMPS)."""
+import ctypes as C, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from sphfluidsimulation_amd import presets, _native as N
+from sphfluidsimulation_amd.simulation import SphFluidSimulation
+n = 16777216; R = presets.scene_bucket_resolution(n)
+pos0, vel0 = presets.dam_break(n, 0.8, 1)
+sim = SphFluidSimulation(particleNumber=n, bucketResolution=R, damFillRate=0.8).Start(pos0, vel0)
+sim.step_n(presets.bench_dt_frame(R), 4)
+nb = ((R + 3) // 4) ** 3
+buf = np.zeros((nb, 8), np.uint64)
+L = N.lib(); L.sph_debug_read_order.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+assert L.sph_debug_read_order(sim._ctx, buf.ctypes.data_as(C.c_void_p), buf.nbytes) == 0
+b = buf[buf[:, 4] > 0].astype(np.int64)
+print("bricks with targets:", len(b), "of", nb)
+for name, a, c in (("setup", 0, 1), ("scan", 1, 2), ("phase2", 2, 3), ("integrate+store", 3, 4), ("total", 0, 4)):
+    dt = (b[:, c] - b[:, a])
+    print(f"{name:16s} mean {dt.mean():9.0f} cycles  median {np.median(dt):9.0f}  p90 {np.percentile(dt, 90):9.0f}  ({dt.mean()/100:.1f} us at 100 MHz ticks?)")
+span = b[:, 4].max() - b[:, 0].min()
+print("kernel span (ticks):", span)

@@ -46,32 +46,38 @@ struct Force {
 };
 
 // VelPos.compute:86-95 for one listed candidate j != i whose fields are already in registers.
+// `take` = false turns the candidate into a no-op (self / padding).  Written WITHOUT branches: a
+// dependent fp32 instruction issues only every ~8 cycles on gfx950 and the sweeps run at 3 waves per
+// SIMD, so the seven IEEE divisions and the sqrt must be independent straight-line chains the
+// scheduler can interleave.  The reference's guards become selects of an exact 0.0f; adding +0.0f
+// to an accumulator that is never -0 is the same as not adding (see sph_kernels_sweep.hip).
 __device__ __forceinline__ void pair_force_vals(const Dev &d, float rx, float ry, float rz, float rho_j,
                                                 float vjx, float vjy, float vjz, float vix, float viy,
-                                                float viz, float p_i, Force &f)
+                                                float viz, float p_i, Force &f, bool take = true)
 {
     const float epsilon = 1e-6f;                                                 // :5
     const float h = d.h;
     const float p_j = d.gas_const * (rho_j - d.rest_density);                    // :87
-    if (rho_j > epsilon) {                                                       // :91
-        const float abs_r = sqrtf((rx * rx + ry * ry) + rz * rz);                // :35, :42
-        const float diff_r = h - abs_r;                                          // :36
-        float gpx = 0.0f, gpy = 0.0f, gpz = 0.0f;
-        if ((epsilon < diff_r) && (epsilon < abs_r)) {                           // :37
-            const float sc = d.c_over_h6 * ((diff_r * diff_r) * diff_r);
-            gpx = (sc * rx) / abs_r;
-            gpy = (sc * ry) / abs_r;
-            gpz = (sc * rz) / abs_r;
-        }
-        const float cp = (p_i + p_j) / (2.0f * rho_j);                           // :93
-        f.px += cp * gpx;
-        f.py += cp * gpy;
-        f.pz += cp * gpz;
-        const float gv = abs_r < h ? d.c_over_h6 * (h - abs_r) : 0.0f;           // :43
-        f.vx += ((vjx - vix) / rho_j) * gv;                                      // :94
-        f.vy += ((vjy - viy) / rho_j) * gv;
-        f.vz += ((vjz - viz) / rho_j) * gv;
-    }
+    const bool ok = take && (rho_j > epsilon);                                   // :91
+    const float abs_r = sqrtf((rx * rx + ry * ry) + rz * rz);                    // :35, :42
+    const float diff_r = h - abs_r;                                              // :36
+    const bool in_p = (epsilon < diff_r) && (epsilon < abs_r);                   // :37
+    const float sc = d.c_over_h6 * ((diff_r * diff_r) * diff_r);
+    const float gpx = in_p ? (sc * rx) / abs_r : 0.0f;
+    const float gpy = in_p ? (sc * ry) / abs_r : 0.0f;
+    const float gpz = in_p ? (sc * rz) / abs_r : 0.0f;
+    const float cp = (p_i + p_j) / (2.0f * rho_j);                               // :93
+    const float gv = abs_r < h ? d.c_over_h6 * (h - abs_r) : 0.0f;               // :43
+    const float tx = cp * gpx, ty = cp * gpy, tz = cp * gpz;
+    const float ux = ((vjx - vix) / rho_j) * gv;                                 // :94
+    const float uy = ((vjy - viy) / rho_j) * gv;
+    const float uz = ((vjz - viz) / rho_j) * gv;
+    f.px += ok ? tx : 0.0f;
+    f.py += ok ? ty : 0.0f;
+    f.pz += ok ? tz : 0.0f;
+    f.vx += ok ? ux : 0.0f;
+    f.vy += ok ? uy : 0.0f;
+    f.vz += ok ? uz : 0.0f;
 }
 
 __device__ __forceinline__ void pair_force(const Dev &d, uint32_t j, float pix, float piy, float piz,
