@@ -759,4 +759,16 @@ int sph_slab_download(SphContext *c, uint32_t cap, uint32_t *ids, float *pos4, f
     return SPH_OK;
 }
 
+
+#ifdef SPH_STAMPS   /* diagnostic builds only: raw read of the sort scratch (holds the phase stamps) */
+int sph_debug_read_order(SphContext *c, void *dst, size_t bytes)
+{
+    if (!c || !dst) return SPH_E_INVALID_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemcpy(dst, c->dev.order, bytes, hipMemcpyDeviceToHost));
+    return SPH_OK;
+}
+#endif
+
 }  // extern "C"
