@@ -28,8 +28,9 @@ public:
 
     ~SphFluidSimulation() { OnDestroy(); }
 
-    // :82-94; the reference fills the position texture with InitParticles.compute, here the caller
-    // hands the float4 arrays (id = y*res + x).  velocities may be nullptr (ClearFloat4, :189).
+    // :82-94; the reference fills the position texture with InitParticles.compute: pass positions == nullptr for
+    // that (row f1, on the device), or hand the float4 arrays (id = y*res + x).  velocities may be nullptr
+    // (ClearFloat4, :189).
     void Start(const float *positions, const float *velocities)
     {
         SphParams p = params();
@@ -41,8 +42,14 @@ public:
         _effectiveRadius = d.effective_radius;            // :159
         _particleMass = d.particle_mass;                  // :176
         count_ = d.particle_count;
-        check(sph_upload(ctx_, positions, velocities));
+        if (positions)
+            check(sph_upload(ctx_, positions, velocities));
+        else
+            check(sph_init_particles(ctx_, preset));      // :179-189, InitParticles.compute kernel #preset
     }
+
+    // Start() exactly as the reference does it: positions from InitParticles.compute, velocities cleared
+    void Start() { Start(nullptr, nullptr); }
 
     // :96-102 with Time.deltaTime = deltaTime
     void Update(float deltaTime) { check(sph_step(ctx_, deltaTime)); }

@@ -128,6 +128,12 @@ int sph_destroy(SphContext *ctx);
  * pos4/vel4: res*res float4, id order.  vel4 may be NULL (= all zero, :189). */
 int sph_upload(SphContext *ctx, const float *pos4, const float *vel4);
 
+/* Row f1: fills the position texture like InitParticles.compute does (kernel index = preset,
+ * SphFluidSimulation.cs:179-184: 0 Preset1 dam break :10-41, 1 Preset2 :43-74, 2 Preset3 :76-107, with the
+ * diagonal simplex-noise jitter of noiseSimplex.cginc::snoise(float4)) and clears the velocities (:189),
+ * on the device, without a host round trip.  Replaces sph_upload for callers that start like the reference. */
+int sph_init_particles(SphContext *ctx, int preset);
+
 /* Reads back the Read textures (+ _particleDensityTexture).  Any pointer may be NULL. */
 int sph_download(SphContext *ctx, float *pos4, float *vel4, float *rho);
 

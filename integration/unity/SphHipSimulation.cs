@@ -11,6 +11,7 @@ using UnityEngine;
 public class SphHipSimulation : MonoBehaviour
 {
     [Header("Initialization")]
+    [Range(0, 2)] public int preset = 1;                 // InitParticles.compute kernel index, SphFluidSimulation.cs:35
     [Range(1024, 4194304)] public int particleNumber = 1024;
     [Range(1, 256)] public int bucketResolution = 256;
     [Range(0.01f, 1f)] public float damFillRate = 0.5f;
@@ -44,9 +45,9 @@ public class SphHipSimulation : MonoBehaviour
         return p;
     }
 
-    /// initialPositions: res*res float4 in texel order (id = y*res + x), e.g. read back once from the
-    /// reference's InitParticles.compute output with Texture2D.GetRawTextureData<float>().
-    public void Begin(float[] initialPositions)
+    /// initialPositions: res*res float4 in texel order (id = y*res + x); null = let the library run the reference's
+    /// InitParticles.compute preset itself (sph_init_particles, kernel index = preset as in SphFluidSimulation.cs:184).
+    public void Begin(float[] initialPositions = null)
     {
         _p = Params();
         SphNative.Check(SphNative.sph_create(ref _p, out _ctx), IntPtr.Zero);
@@ -55,7 +56,10 @@ public class SphHipSimulation : MonoBehaviour
         _res = (int)d.particle_resolution;              // :85
         _pos = new float[4 * d.particle_count];
         _vel = new float[4 * d.particle_count];
-        SphNative.Check(SphNative.sph_upload(_ctx, initialPositions, null), _ctx);   // velocities start at zero, :189
+        if (initialPositions != null)
+            SphNative.Check(SphNative.sph_upload(_ctx, initialPositions, null), _ctx);   // velocities start at zero, :189
+        else
+            SphNative.Check(SphNative.sph_init_particles(_ctx, preset), _ctx);           // :179-189
     }
 
     void Update()

@@ -56,6 +56,7 @@ public static class SphNative
     [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int sph_create(ref SphParams p, out IntPtr ctx);
     [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int sph_destroy(IntPtr ctx);
     [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int sph_upload(IntPtr ctx, float[] pos4, float[] vel4);
+    [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int sph_init_particles(IntPtr ctx, int preset);
     [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int sph_download(IntPtr ctx, float[] pos4, float[] vel4, float[] rho);
     [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int sph_step(IntPtr ctx, float deltaTime);
     [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int sph_step_n(IntPtr ctx, float deltaTime, int frames);

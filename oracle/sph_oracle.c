@@ -488,3 +488,147 @@ void oracle_sim_update(OracleSim *s, float delta_time)
 }
 
 const uint32_t *oracle_sim_bucket(const OracleSim *s) { return s->bucket; }
+
+/* ======================================================================================
+ * Row f1: initial-condition generator.
+ *   Assets/Resources/InitParticles.compute:10-107   Preset1/2/3   -> oracle_init_particles()
+ *   Assets/Resources/noiseSimplex.cginc:62-126,296-425  mod289, permute, taylorInvSqrt, grad4,
+ *                                                        snoise(float4) -> oracle_snoise4()
+ * Same floating-point contract as above.  The one transcendental, pow(count/fill, 1/3) at
+ * InitParticles.compute:20,53,86, is evaluated by the CALLER (float powf) and passed in as
+ * particle_per_dim, so oracle and engine cannot disagree on it.
+ * ====================================================================================== */
+
+typedef struct { float x, y, z, w; } f4;
+
+static inline float fracf_(float x) { return x - floorf(x); }
+static inline float step_(float y, float x) { return x >= y ? 1.0f : 0.0f; }          /* HLSL step(y, x) */
+static inline float saturate_(float x) { return fminf(fmaxf(x, 0.0f), 1.0f); }
+static inline float dot4(f4 a, f4 b) { return ((a.x * b.x + a.y * b.y) + a.z * b.z) + a.w * b.w; }
+static inline float mod289f(float x) { return x - floorf(x * 0.00346020761245674740484429065744f) * 289.0f; } /* :65-67 */
+static inline float permutef(float x) { return mod289f(x * x * 34.0f + x); }          /* :85-89 */
+static inline float taylor_inv_sqrt(float r) { return 1.79284291400159f - 0.85373472095314f * r; } /* :105-107 */
+
+static f4 grad4(float j, f4 ip)                                                       /* :115-130 */
+{
+    f4 p, s;
+    p.x = floorf(fracf_(j * ip.x) * 7.0f) * ip.z - 1.0f;
+    p.y = floorf(fracf_(j * ip.y) * 7.0f) * ip.z - 1.0f;
+    p.z = floorf(fracf_(j * ip.z) * 7.0f) * ip.z - 1.0f;
+    p.w = 1.5f - ((fabsf(p.x) * 1.0f + fabsf(p.y) * 1.0f) + fabsf(p.z) * 1.0f);
+    s.x = 1.0f - step_(0.0f, p.x);
+    s.y = 1.0f - step_(0.0f, p.y);
+    s.z = 1.0f - step_(0.0f, p.z);
+    s.w = 1.0f - step_(0.0f, p.w);
+    p.x = p.x + (s.x * 2.0f - 1.0f) * s.w;
+    p.y = p.y + (s.y * 2.0f - 1.0f) * s.w;
+    p.z = p.z + (s.z * 2.0f - 1.0f) * s.w;
+    return p;
+}
+
+float oracle_snoise4(float vx, float vy, float vz, float vw)                           /* :296-425 */
+{
+    const float Cx = 0.138196601125011f, Cy = 0.276393202250021f, Cz = 0.414589803375032f, Cw = -0.447213595499958f;
+    const float F4 = 0.309016994374947451f;
+    const f4 v = {vx, vy, vz, vw};
+    const float sk = ((v.x * F4 + v.y * F4) + v.z * F4) + v.w * F4;                   /* dot(v, F4) :309-312 */
+    f4 i = {floorf(v.x + sk), floorf(v.y + sk), floorf(v.z + sk), floorf(v.w + sk)};
+    const float un = ((i.x * Cx + i.y * Cx) + i.z * Cx) + i.w * Cx;                   /* dot(i, C.xxxx) :315 */
+    const f4 x0 = {v.x - i.x + un, v.y - i.y + un, v.z - i.z + un, v.w - i.w + un};
+    /* rank sorting :320-329 */
+    const float isXx = step_(x0.y, x0.x), isXy = step_(x0.z, x0.x), isXz = step_(x0.w, x0.x);
+    const float isYZx = step_(x0.z, x0.y), isYZy = step_(x0.w, x0.y), isYZz = step_(x0.w, x0.z);
+    f4 i0;
+    i0.x = isXx + isXy + isXz;
+    i0.y = 1.0f - isXx;
+    i0.z = 1.0f - isXy;
+    i0.w = 1.0f - isXz;
+    i0.y += isYZx + isYZy;
+    i0.z += 1.0f - isYZx;
+    i0.w += 1.0f - isYZy;
+    i0.z += isYZz;
+    i0.w += 1.0f - isYZz;
+    const f4 i3 = {saturate_(i0.x), saturate_(i0.y), saturate_(i0.z), saturate_(i0.w)};
+    const f4 i2 = {saturate_(i0.x - 1.0f), saturate_(i0.y - 1.0f), saturate_(i0.z - 1.0f), saturate_(i0.w - 1.0f)};
+    const f4 i1 = {saturate_(i0.x - 2.0f), saturate_(i0.y - 2.0f), saturate_(i0.z - 2.0f), saturate_(i0.w - 2.0f)};
+    const f4 x1 = {x0.x - i1.x + Cx, x0.y - i1.y + Cx, x0.z - i1.z + Cx, x0.w - i1.w + Cx};   /* :341-344 */
+    const f4 x2 = {x0.x - i2.x + Cy, x0.y - i2.y + Cy, x0.z - i2.z + Cy, x0.w - i2.w + Cy};
+    const f4 x3 = {x0.x - i3.x + Cz, x0.y - i3.y + Cz, x0.z - i3.z + Cz, x0.w - i3.w + Cz};
+    const f4 x4 = {x0.x + Cw, x0.y + Cw, x0.z + Cw, x0.w + Cw};
+    /* permutations :347-364 */
+    i.x = mod289f(i.x); i.y = mod289f(i.y); i.z = mod289f(i.z); i.w = mod289f(i.w);
+    const float j0 = permutef(permutef(permutef(permutef(i.w) + i.z) + i.y) + i.x);
+    float j1[4];
+    const float aw[4] = {i1.w, i2.w, i3.w, 1.0f}, az[4] = {i1.z, i2.z, i3.z, 1.0f};
+    const float ay[4] = {i1.y, i2.y, i3.y, 1.0f}, ax[4] = {i1.x, i2.x, i3.x, 1.0f};
+    for (int k = 0; k < 4; k++)
+        j1[k] = permutef(permutef(permutef(permutef(i.w + aw[k]) + i.z + az[k]) + i.y + ay[k]) + i.x + ax[k]);
+    const f4 ip = {0.003401360544217687075f, 0.020408163265306122449f, 0.142857142857142857143f, 0.0f}; /* :368-373 */
+    f4 p0 = grad4(j0, ip), p1 = grad4(j1[0], ip), p2 = grad4(j1[1], ip), p3 = grad4(j1[2], ip), p4 = grad4(j1[3], ip);
+    const float n0 = taylor_inv_sqrt(dot4(p0, p0)), n1 = taylor_inv_sqrt(dot4(p1, p1));     /* :382-393 */
+    const float n2 = taylor_inv_sqrt(dot4(p2, p2)), n3 = taylor_inv_sqrt(dot4(p3, p3));
+    p0.x *= n0; p0.y *= n0; p0.z *= n0; p0.w *= n0;
+    p1.x *= n1; p1.y *= n1; p1.z *= n1; p1.w *= n1;
+    p2.x *= n2; p2.y *= n2; p2.z *= n2; p2.w *= n2;
+    p3.x *= n3; p3.y *= n3; p3.z *= n3; p3.w *= n3;
+    const float n4 = taylor_inv_sqrt(dot4(p4, p4));
+    p4.x *= n4; p4.y *= n4; p4.z *= n4; p4.w *= n4;
+    float m00 = fmaxf(0.6f - dot4(x0, x0), 0.0f), m01 = fmaxf(0.6f - dot4(x1, x1), 0.0f);   /* :396-412 */
+    float m02 = fmaxf(0.6f - dot4(x2, x2), 0.0f);
+    float m10 = fmaxf(0.6f - dot4(x3, x3), 0.0f), m11 = fmaxf(0.6f - dot4(x4, x4), 0.0f);
+    m00 = m00 * m00; m01 = m01 * m01; m02 = m02 * m02;
+    m10 = m10 * m10; m11 = m11 * m11;
+    const float d0 = dot4(p0, x0), d1 = dot4(p1, x1), d2 = dot4(p2, x2), d3 = dot4(p3, x3), d4 = dot4(p4, x4);
+    const float a = ((m00 * m00) * d0 + (m01 * m01) * d1) + (m02 * m02) * d2;               /* dot(float3) */
+    const float b = (m10 * m10) * d3 + (m11 * m11) * d4;                                    /* dot(float2) */
+    return 49.0f * (a + b);                                                                 /* :414-424 */
+}
+
+/* InitParticles.compute: Preset1 :10-41 (preset 0), Preset2 :43-74 (1), Preset3 :76-107 (2).
+ * noise_on = 0 skips :37/:70/:103 (test aid). */
+int oracle_init_particles(int preset, uint32_t res, float fill, uint32_t particle_per_dim, int noise_on, float *pos4)
+{
+    if (preset < 0 || preset > 2 || particle_per_dim == 0 || !pos4) return -1;
+    const uint32_t ppd = particle_per_dim;
+    const uint32_t xSize = (uint32_t)ceilf((float)ppd * fill);                          /* :22,:55,:88 */
+    const uint32_t ySize = ppd;
+    const uint32_t zSize = preset == 0 ? ppd : (uint32_t)ceilf((float)ppd * fill);      /* :24,:57,:90 */
+    const float cs = 1.0f / (float)ppd;                                                 /* :26 */
+    for (uint32_t y = 0; y < res; y++)
+        for (uint32_t x = 0; x < res; x++) {
+            const int32_t i = (int32_t)(x + y * res);                                   /* :28 */
+            const uint32_t ui = (uint32_t)i;
+            f4 pos;
+            const float qx = (float)(ui / (zSize * ySize)), qy = (float)((ui / zSize) % ySize), qz = (float)(ui % zSize);
+            if (preset == 0) {                                                          /* :30-35 */
+                pos.x = cs / 2.0f + qx * fill / (float)xSize;
+                pos.y = cs / 2.0f + qy * 0.9f / (float)ySize;
+                pos.z = cs / 2.0f + qz * 1.0f / (float)zSize;
+            } else if (preset == 1) {                                                   /* :63-68 */
+                pos.x = cs / 2.0f + fill / 2.0f + qx * fill / (float)xSize;
+                pos.y = cs / 2.0f + qy * 0.9f / (float)ySize;
+                pos.z = cs / 2.0f + fill / 2.0f + qz * fill / (float)zSize;
+            } else {                                                                    /* :96-101 */
+                pos.x = cs / 2.0f + qx * fill / (float)xSize;
+                pos.y = cs / 2.0f + qy * 0.9f / (float)ySize;
+                pos.z = cs / 2.0f + qz * fill / (float)zSize;
+            }
+            pos.w = 1.0f;
+            if (noise_on) {                                                             /* :37 pos += snoise(pos + i) * cs */
+                const float fi = (float)i;
+                const float nz = oracle_snoise4(pos.x + fi, pos.y + fi, pos.z + fi, pos.w + fi) * cs;
+                pos.x += nz; pos.y += nz; pos.z += nz;
+            }
+            float *o = pos4 + 4ull * (size_t)ui;
+            o[0] = pos.x; o[1] = pos.y; o[2] = pos.z; o[3] = 1.0f;                      /* :38 */
+        }
+    return 0;
+}
+
+/* InitParticles.compute:20 / :53,:86: uint(ceil(pow(particleCount / fill[^2], 1.0/3.0))) in fp32 (libm powf). */
+uint32_t oracle_particle_per_dim(int preset, uint32_t res, float fill)
+{
+    const float count = (float)(res * res);
+    const float denom = preset == 0 ? fill : fill * fill;
+    return (uint32_t)ceilf(powf(count / denom, 1.0f / 3.0f));
+}

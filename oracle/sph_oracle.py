@@ -84,6 +84,12 @@ def lib() -> C.CDLL:
         L.oracle_sim_update.argtypes = [C.c_void_p, C.c_float]
         L.oracle_sim_bucket.argtypes = [C.c_void_p]
         L.oracle_sim_bucket.restype = up
+        L.oracle_snoise4.argtypes = [C.c_float] * 4
+        L.oracle_snoise4.restype = C.c_float
+        L.oracle_init_particles.argtypes = [C.c_int, C.c_uint32, C.c_float, C.c_uint32, C.c_int, fp]
+        L.oracle_init_particles.restype = C.c_int
+        L.oracle_particle_per_dim.argtypes = [C.c_int, C.c_uint32, C.c_float]
+        L.oracle_particle_per_dim.restype = C.c_uint32
         _lib = L
     return _lib
 
@@ -196,3 +202,30 @@ def velpos(p: OracleParams, pos4, vel4, rho, bucket, dt: float):
     lib().oracle_velpos(C.byref(p), _fp(pos4), _fp(vel4), _fp(rho), _up(bucket), _fp(po), _fp(vo),
                         float(np.float32(dt)))
     return po, vo
+
+
+# ---- row f1: InitParticles.compute presets + noiseSimplex.cginc::snoise(float4) -------------------------
+
+def particle_per_dim(preset: int, res: int, fill: float) -> int:
+    """InitParticles.compute:20 (Preset1) / :53,:86 (Preset2/3): uint(ceil(pow(count / fill[^2], 1/3))), the one
+    transcendental of the generator, evaluated once in fp32 here for oracle AND engine."""
+    return int(lib().oracle_particle_per_dim(preset, res, float(np.float32(fill))))
+
+
+def snoise4(x, y=None, z=None, w=None):
+    """noiseSimplex.cginc::snoise(float4): four scalars -> float, or an (n, 4) array -> (n,) float32."""
+    f = lib().oracle_snoise4
+    if y is None:
+        v = np.ascontiguousarray(x, dtype=np.float32).reshape(-1, 4)
+        return np.array([f(float(a), float(b), float(c), float(d)) for a, b, c, d in v], dtype=np.float32)
+    return float(f(float(np.float32(x)), float(np.float32(y)), float(np.float32(z)), float(np.float32(w))))
+
+
+def init_particles(preset: int, res: int, fill: float, noise: bool = True) -> np.ndarray:
+    """preset = kernel index as in SphFluidSimulation.cs:184 (0 Preset1 dam break, 1 Preset2, 2 Preset3)."""
+    pos = np.empty((res * res, 4), np.float32)
+    rc = lib().oracle_init_particles(preset, res, float(np.float32(fill)), particle_per_dim(preset, res, fill),
+                                     1 if noise else 0, _fp(pos))
+    if rc != 0:
+        raise ValueError("oracle_init_particles: invalid arguments")
+    return pos

@@ -103,6 +103,7 @@ SYMBOLS = {
     "sph_destroy": (C.c_int, [_CTX]),
     "sph_upload": (C.c_int, [_CTX, _FP, _FP]),
     "sph_download": (C.c_int, [_CTX, _FP, _FP, _FP]),
+    "sph_init_particles": (C.c_int, [_CTX, C.c_int]),
     "sph_step": (C.c_int, [_CTX, C.c_float]),
     "sph_step_n": (C.c_int, [_CTX, C.c_float, C.c_int]),
     "sph_bucket_generation": (C.c_int, [_CTX]),

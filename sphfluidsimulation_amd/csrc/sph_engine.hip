@@ -430,6 +430,30 @@ int sph_upload(SphContext *c, const float *pos4, const float *vel4)
     return SPH_OK;
 }
 
+int sph_init_particles(SphContext *c, int preset)
+{
+    if (!c) return fail(nullptr, SPH_E_INVALID_ARG, "ctx is NULL");
+    if (c->slab) return fail(c, SPH_E_BAD_STATE, "slab context: initialise on the host and use sph_slab_upload");
+    if (preset < 0 || preset > 2) return fail(c, SPH_E_INVALID_ARG, "preset %d not in [0,2] (SphFluidSimulation.cs:35)", preset);
+    HIP_TRY(c, hipSetDevice(c->device));
+    const uint32_t res = c->derived.particle_resolution;
+    const float fill = c->params.dam_fill_rate;
+    // InitParticles.compute:20 / :53,:86: uint(ceil(pow(count / fill[^2], 1/3))), fp32
+    const float denom = preset == 0 ? fill : fill * fill;
+    const uint32_t ppd = (uint32_t)ceilf(powf((float)(res * res) / denom, 1.0f / 3.0f));
+    if (ppd == 0) return fail(c, SPH_E_INVALID_ARG, "dam_fill_rate %g gives an empty lattice", (double)fill);
+    launch_init_particles(preset, res, fill, ppd, c->pos4_dev, c->stream);
+    HIP_TRY(c, hipMemsetAsync(c->dev.counters + kCntWildP, 0, sizeof(unsigned long long) * 3, c->stream));
+    c->dev.wild_v_cur = 0;
+    c->dev.force_slow = 0;
+    launch_upload_split(c->dev, c->pos4_dev, nullptr, c->pw0, c->stream);   // velocities cleared, SphFluidSimulation.cs:189
+    HIP_TRY(c, hipGetLastError());
+    c->uploaded = true;
+    c->grid_valid = false;
+    c->substeps_since_upload = 0;
+    return SPH_OK;
+}
+
 int sph_download(SphContext *c, float *pos4, float *vel4, float *rho)
 {
     if (!c) return fail(nullptr, SPH_E_INVALID_ARG, "ctx is NULL");

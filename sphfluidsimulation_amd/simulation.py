@@ -68,8 +68,9 @@ class SphFluidSimulation:
               seed: int = 1):
         """SphFluidSimulation.cs:82-94.  The reference fills the position texture with
         InitParticles.compute (kernel index = preset) and clears the velocity texture; here the
-        caller passes the float4 arrays, or gets the synthetic dam-break of presets.dam_break
-        (Preset1 lattice, hash jitter)."""
+        caller passes the float4 arrays, gets the synthetic dam-break of presets.dam_break (Preset1 lattice,
+        hash jitter, `seed`), or -- with seed=None -- the reference's own generator on the device
+        (sph_init_particles: kernel index = self.preset, simplex-noise jitter)."""
         p = self._params()
         self._check(N.lib().sph_create(C.byref(p), C.byref(self._ctx)))
         d = N.SphDerived()
@@ -79,6 +80,10 @@ class SphFluidSimulation:
         self._particleTextureResolution = d.particle_resolution  # :85
         self._effectiveRadius = d.effective_radius               # :159
         self._particleMass = d.particle_mass                     # :176
+        if positions is None and seed is None:
+            # exactly like the reference: InitParticles.compute kernel #preset + cleared velocities (:179-189)
+            self._check(N.lib().sph_init_particles(self._ctx, int(self.preset)))
+            return self
         if positions is None:
             positions, velocities = presets.dam_break(self.particleNumber, self.damFillRate, seed)
         self.upload(positions, velocities)
