@@ -132,6 +132,14 @@ def main():
     elapsed = time.perf_counter() - t0
 
     st = sim.stats()
+    # row f3, the render feed after the path (UpdateMeshProperties, never part of `value`): 112 B per particle
+    sim.UpdateMeshProperties()
+    sim.synchronize()
+    tm = time.perf_counter()
+    for _ in range(20):
+        sim.UpdateMeshProperties()
+    sim.synchronize()
+    mesh_ms = (time.perf_counter() - tm) * 1e3 / 20
     # boundary cost when the caller hands over HOST arrays every frame (never part of `value`)
     t1 = time.perf_counter()
     sim.upload(frame1[0], frame1[1])
@@ -166,6 +174,9 @@ def main():
         "particle_substeps_per_s": value * 5,
         "host_boundary": {"upload_ms": (t2 - t1) * 1e3, "download_ms": (t3 - t2) * 1e3,
                           "pcie_inclusive_particle_steps_per_s": n / (elapsed / a.steps + (t3 - t1))},
+        "render_feed": {"kernel": "k_mesh_properties", "ms": mesh_ms, "algorithmic_bytes": 112 * n,
+                        "achieved_GBs": 112 * n / (mesh_ms * 1e-3) / 1e9,
+                        "hbm_frac": 112 * n / (mesh_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
         "max_cell_occupancy": st["max_cell_occupancy"], "nan_resets": st["nan_resets"],
         "queued_targets_last_sweep": st["queued_targets"],
     }

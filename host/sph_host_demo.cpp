@@ -40,6 +40,16 @@ int main(int argc, char **argv)
             for (int a = 0; a < 3; a++)
                 if (!(p[4 * i + a] >= 0.0f && p[4 * i + a] <= 1.0f)) bad++;      // clamp, VelPos.compute:154
         }
+        // row f3: render feed from the same state; identity _SimTRS -> mat = translate(pos - 0.5) * scale(radius)
+        sim.UpdateMeshProperties();
+        std::vector<float> props(20 * (size_t)sim.count());
+        sim.DownloadMeshProperties(props.data());
+        for (unsigned i = 0; i < sim.count(); i++) {
+            const float *r = &props[20 * (size_t)i];
+            for (int a = 0; a < 3; a++)
+                if (r[12 + a] != p[4 * i + a] * 1.0f - 0.5f || r[5 * a] != sim.particleRadius) bad++;
+            if (r[15] != 1.0f || r[19] != 1.0f || r[17] != 0.0f || r[18] != 1.0f - r[16]) bad++;
+        }
         SphStats st = sim.Stats();
         printf("host demo: N=%u frames=%d max_cell_occupancy=%u nan_resets=%llu violations=%d\n", sim.count(), frames,
                st.max_cell_occupancy, (unsigned long long)st.nan_resets, bad);

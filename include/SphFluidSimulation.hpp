@@ -24,6 +24,8 @@ public:
     float gasConstant = 150.0f;
     float stiffnessCoefficient = 5000.0f;
     float dampingCoefficient = 10.0f;
+    // rendering fields :49-53 (SampleScene.unity:372-376)
+    float particleRadius = 0.01f, lowSpeed = 0.0f, highSpeed = 0.5f;
     int deviceId = 0;
 
     ~SphFluidSimulation() { OnDestroy(); }
@@ -60,6 +62,21 @@ public:
         if (ctx_) sph_destroy(ctx_);
         ctx_ = nullptr;
     }
+
+    // :271-284 (row f3): fills the device-side _particleMeshPropertiesBuffer; simTRS = transform.localToWorldMatrix,
+    // column-major like UnityEngine.Matrix4x4 (nullptr = identity)
+    void UpdateMeshProperties(const float *simTRS = nullptr)
+    {
+        SphMeshParams m{};
+        m.struct_size = sizeof(SphMeshParams);
+        m.low_speed = lowSpeed;
+        m.high_speed = highSpeed;
+        for (int k = 0; k < 3; k++) m.particle_scale[k] = particleRadius;   // :280
+        for (int k = 0; k < 16; k++) m.sim_trs[k] = simTRS ? simTRS[k] : (k % 5 == 0 ? 1.0f : 0.0f);
+        check(sph_update_mesh_properties(ctx_, &m));
+    }
+    // 20 floats per particle (MeshProperties, :16-29), record index = texel id
+    void DownloadMeshProperties(float *props20) { check(sph_download_mesh_properties(ctx_, props20)); }
 
     void BucketGeneration() { check(sph_bucket_generation(ctx_)); }                          // :203-221
     void DensityCalculation() { check(sph_density_calculation(ctx_)); }                      // :223-241

@@ -137,6 +137,25 @@ int sph_init_particles(SphContext *ctx, int preset);
 /* Reads back the Read textures (+ _particleDensityTexture).  Any pointer may be NULL. */
 int sph_download(SphContext *ctx, float *pos4, float *vel4, float *rho);
 
+/* Row f3, the render feed after the path: UpdateMeshProperties() (SphFluidSimulation.cs:104, :271-284 driving
+ * UpdateMeshProperties.compute:18-64).  Fills the context's _particleMeshPropertiesBuffer (:174) on the device from
+ * the current Read state: record `id` = MeshProperties (:16-29) = float4x4 mat (column-major memory order, as HLSL
+ * packs it and UnityEngine.Matrix4x4 stores it) = translate(pos * simScale - simScale/2) x scale(particle_scale),
+ * then float4 color = lerp(blue, red, saturate((|vel| - low) / (high - low))): 20 floats = 80 bytes. */
+typedef struct SphMeshParams {
+    uint32_t struct_size;      /* = sizeof(SphMeshParams) */
+    float low_speed;           /* lowSpeed  :52, :278 */
+    float high_speed;          /* highSpeed :53, :277 */
+    float particle_scale[3];   /* (particleRadius, particleRadius, particleRadius) :280 */
+    float sim_trs[16];         /* transform.localToWorldMatrix :281, column-major (Matrix4x4 memory order) */
+} SphMeshParams;
+#define SPH_MESH_RECORD_FLOATS 20
+int sph_update_mesh_properties(SphContext *ctx, const SphMeshParams *mesh);
+/* Copies the buffer to the host (num_particles x 20 floats); synchronises. */
+int sph_download_mesh_properties(SphContext *ctx, float *props20);
+/* The device buffer itself (valid until sph_destroy), for a renderer that can import device memory (row f4). */
+int sph_mesh_properties_device_ptr(SphContext *ctx, void **device_ptr, size_t *bytes);
+
 /* One Update() (SphFluidSimulation.cs:96-102) with Time.deltaTime = delta_time:
  * BucketGeneration, DensityCalculation, substeps x UpdateVelocityAndPosition(delta_time/25). */
 int sph_step(SphContext *ctx, float delta_time);

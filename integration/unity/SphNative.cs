@@ -4,6 +4,7 @@
 // (host/sph_host_demo.cpp) and Python ctypes (sphfluidsimulation_amd/_native.py).
 using System;
 using System.Runtime.InteropServices;
+using UnityEngine;   // Matrix4x4 in SphMeshParams
 
 public static class SphNative
 {
@@ -57,6 +58,19 @@ public static class SphNative
     [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int sph_destroy(IntPtr ctx);
     [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int sph_upload(IntPtr ctx, float[] pos4, float[] vel4);
     [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int sph_init_particles(IntPtr ctx, int preset);
+
+    // row f3: UpdateMeshProperties() :271-284.  sim_trs = transform.localToWorldMatrix, column-major = Matrix4x4's own field order
+    [StructLayout(LayoutKind.Sequential)]
+    public struct SphMeshParams
+    {
+        public uint struct_size;
+        public float low_speed, high_speed;
+        public float scale_x, scale_y, scale_z;
+        public Matrix4x4 sim_trs;
+    }
+    [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int sph_update_mesh_properties(IntPtr ctx, ref SphMeshParams mesh);
+    [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int sph_download_mesh_properties(IntPtr ctx, [Out] float[] props20);
+    [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int sph_mesh_properties_device_ptr(IntPtr ctx, out IntPtr devicePtr, out UIntPtr bytes);
     [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int sph_download(IntPtr ctx, float[] pos4, float[] vel4, float[] rho);
     [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int sph_step(IntPtr ctx, float deltaTime);
     [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int sph_step_n(IntPtr ctx, float deltaTime, int frames);

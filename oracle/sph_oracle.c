@@ -632,3 +632,37 @@ uint32_t oracle_particle_per_dim(int preset, uint32_t res, float fill)
     const float denom = preset == 0 ? fill : fill * fill;
     return (uint32_t)ceilf(powf(count / denom, 1.0f / 3.0f));
 }
+
+/* ============================== row f3: UpdateMeshProperties.compute =====================================
+ * The render feed that follows the path (SphFluidSimulation.cs:104, :271-284): per texel, a translate x scale
+ * 4x4 and a blue->red speed colour (UpdateMeshProperties.compute:20-64).  Record = MeshProperties
+ * (SphFluidSimulation.cs:16-29): float4x4 mat in column-major memory order (HLSL's default packing, and what
+ * UnityEngine.Matrix4x4 holds: m00,m10,m20,m30, m01,...), then float4 color: 20 floats = 80 bytes.
+ * sim_trs = transform.localToWorldMatrix in that same column-major order (:281).
+ * mul(translation, scale) is evaluated as the literal 4-term sums, so a non-finite position poisons its row
+ * exactly as IEEE says (0 * inf = NaN); the products with 0 and 1 are otherwise exact. */
+
+void oracle_update_mesh_properties(uint32_t count, const float *pos4, const float *vel4, float low_speed,
+                                   float high_speed, const float *particle_scale3, const float *sim_trs16,
+                                   float *props20)
+{
+    /* :35 simScale = (_m00,_m11,_m22); :38 simPosition is read but never used */
+    const float ss[3] = {sim_trs16[0], sim_trs16[5], sim_trs16[10]};
+    const float S[4][4] = {{particle_scale3[0], 0, 0, 0}, {0, particle_scale3[1], 0, 0},
+                           {0, 0, particle_scale3[2], 0}, {0, 0, 0, 1}};                       /* :44-49 */
+#pragma omp parallel for schedule(static)
+    for (int64_t id = 0; id < (int64_t)count; id++) {
+        const float *p = pos4 + 4 * id, *v = vel4 + 4 * id;
+        const float speed = sqrtf((v[0] * v[0] + v[1] * v[1]) + v[2] * v[2]);                  /* :32 */
+        float w[3];
+        for (int k = 0; k < 3; k++) w[k] = p[k] * ss[k] - (ss[k] * 0.5f);                      /* :41 */
+        const float T[4][4] = {{1, 0, 0, w[0]}, {0, 1, 0, w[1]}, {0, 0, 1, w[2]}, {0, 0, 0, 1}}; /* :52-57 */
+        float *o = props20 + 20 * id;
+        for (int r = 0; r < 4; r++)
+            for (int c = 0; c < 4; c++)                                                         /* :60 */
+                o[c * 4 + r] = ((T[r][0] * S[0][c] + T[r][1] * S[1][c]) + T[r][2] * S[2][c]) + T[r][3] * S[3][c];
+        const float t = hlsl_clamp01((speed - low_speed) / (high_speed - low_speed));          /* :63 */
+        const float a[4] = {0, 0, 1, 1}, b[4] = {1, 0, 0, 1};
+        for (int k = 0; k < 4; k++) o[16 + k] = a[k] + t * (b[k] - a[k]);                       /* :64 lerp(x,y,s)=x+s(y-x) */
+    }
+}

@@ -88,6 +88,8 @@ def lib() -> C.CDLL:
         L.oracle_snoise4.restype = C.c_float
         L.oracle_init_particles.argtypes = [C.c_int, C.c_uint32, C.c_float, C.c_uint32, C.c_int, fp]
         L.oracle_init_particles.restype = C.c_int
+        L.oracle_update_mesh_properties.argtypes = [C.c_uint32, fp, fp, C.c_float, C.c_float, fp, fp, fp]
+        L.oracle_update_mesh_properties.restype = None
         L.oracle_particle_per_dim.argtypes = [C.c_int, C.c_uint32, C.c_float]
         L.oracle_particle_per_dim.restype = C.c_uint32
         _lib = L
@@ -229,3 +231,20 @@ def init_particles(preset: int, res: int, fill: float, noise: bool = True) -> np
     if rc != 0:
         raise ValueError("oracle_init_particles: invalid arguments")
     return pos
+
+
+# ---- row f3: UpdateMeshProperties.compute ---------------------------------------------------------------
+
+def update_mesh_properties(pos4: np.ndarray, vel4: np.ndarray, low_speed: float, high_speed: float,
+                           particle_scale, sim_trs=None) -> np.ndarray:
+    """UpdateMeshProperties.compute:18-64.  sim_trs: 4x4 in (row, column) notation (default identity).
+    Returns (count, 20) float32: column-major mat, then color."""
+    pos4 = np.ascontiguousarray(pos4, dtype=np.float32).reshape(-1, 4)
+    vel4 = np.ascontiguousarray(vel4, dtype=np.float32).reshape(-1, 4)
+    scale = np.ascontiguousarray(np.broadcast_to(np.asarray(particle_scale, np.float32), (3,)))
+    trs = np.eye(4, dtype=np.float32) if sim_trs is None else np.asarray(sim_trs, np.float32).reshape(4, 4)
+    trs_cm = np.ascontiguousarray(trs.T).reshape(-1)
+    out = np.empty((pos4.shape[0], 20), np.float32)
+    lib().oracle_update_mesh_properties(pos4.shape[0], _fp(pos4), _fp(vel4), float(np.float32(low_speed)),
+                                        float(np.float32(high_speed)), _fp(scale), _fp(trs_cm), _fp(out))
+    return out

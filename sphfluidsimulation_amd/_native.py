@@ -93,6 +93,18 @@ class SphStats(C.Structure):
         return {n: getattr(self, n) for n, _ in self._fields_}
 
 
+class SphMeshParams(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32),
+        ("low_speed", C.c_float),
+        ("high_speed", C.c_float),
+        ("particle_scale", C.c_float * 3),
+        ("sim_trs", C.c_float * 16),
+    ]
+
+
+SPH_MESH_RECORD_FLOATS = 20
+
 # every symbol include/sph_hip.h declares: name -> (restype, argtypes)
 _FP = C.POINTER(C.c_float)
 _CTX = C.c_void_p
@@ -104,6 +116,9 @@ SYMBOLS = {
     "sph_upload": (C.c_int, [_CTX, _FP, _FP]),
     "sph_download": (C.c_int, [_CTX, _FP, _FP, _FP]),
     "sph_init_particles": (C.c_int, [_CTX, C.c_int]),
+    "sph_update_mesh_properties": (C.c_int, [_CTX, C.POINTER(SphMeshParams)]),
+    "sph_download_mesh_properties": (C.c_int, [_CTX, _FP]),
+    "sph_mesh_properties_device_ptr": (C.c_int, [_CTX, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
     "sph_step": (C.c_int, [_CTX, C.c_float]),
     "sph_step_n": (C.c_int, [_CTX, C.c_float, C.c_int]),
     "sph_bucket_generation": (C.c_int, [_CTX]),

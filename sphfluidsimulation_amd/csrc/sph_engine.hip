@@ -32,6 +32,8 @@ struct SphContext {
     // staging in the reference's texture layout
     float4 *pos4_dev = nullptr, *vel4_dev = nullptr;
     float *rho_id_dev = nullptr, *pw0 = nullptr;
+    float4 *mesh_props = nullptr;     // _particleMeshPropertiesBuffer (:174), allocated on first use
+    bool mesh_valid = false;
     bool uploaded = false, grid_valid = false;
     int substeps_since_upload = 0;
     float dt_last = 0.0f;
@@ -426,6 +428,7 @@ int sph_upload(SphContext *c, const float *pos4, const float *vel4)
     HIP_TRY(c, hipStreamSynchronize(c->stream));  // the caller's arrays may be freed on return
     c->uploaded = true;
     c->grid_valid = false;
+    c->mesh_valid = false;
     c->substeps_since_upload = 0;
     return SPH_OK;
 }
@@ -450,6 +453,7 @@ int sph_init_particles(SphContext *c, int preset)
     HIP_TRY(c, hipGetLastError());
     c->uploaded = true;
     c->grid_valid = false;
+    c->mesh_valid = false;
     c->substeps_since_upload = 0;
     return SPH_OK;
 }
@@ -468,6 +472,45 @@ int sph_download(SphContext *c, float *pos4, float *vel4, float *rho)
     if (vel4) HIP_TRY(c, hipMemcpyAsync(vel4, c->vel4_dev, n * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
     if (rho) HIP_TRY(c, hipMemcpyAsync(rho, c->rho_id_dev, n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return SPH_OK;
+}
+
+int sph_update_mesh_properties(SphContext *c, const SphMeshParams *m)
+{
+    if (!c) return fail(nullptr, SPH_E_INVALID_ARG, "ctx is NULL");
+    if (!m || m->struct_size != sizeof(SphMeshParams))
+        return fail(c, SPH_E_INVALID_ARG, "SphMeshParams NULL or struct_size != %zu", sizeof(SphMeshParams));
+    if (c->slab) return fail(c, SPH_E_BAD_STATE, "slab context: render feed is built from sph_slab_download output");
+    if (!c->uploaded) return fail(c, SPH_E_BAD_STATE, "sph_update_mesh_properties before sph_upload");
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (!c->mesh_props) {
+        int rc = dalloc(c, &c->mesh_props, (size_t)c->dev.count * 5);
+        if (rc != SPH_OK) return rc;
+    }
+    launch_mesh_properties(c->dev, m->low_speed, m->high_speed, m->particle_scale, m->sim_trs, c->mesh_props, c->stream);
+    HIP_TRY(c, hipGetLastError());
+    c->mesh_valid = true;
+    return SPH_OK;
+}
+
+int sph_download_mesh_properties(SphContext *c, float *props20)
+{
+    if (!c) return fail(nullptr, SPH_E_INVALID_ARG, "ctx is NULL");
+    if (!props20) return fail(c, SPH_E_INVALID_ARG, "props20 is NULL");
+    if (!c->mesh_valid) return fail(c, SPH_E_BAD_STATE, "sph_download_mesh_properties before sph_update_mesh_properties");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipMemcpyAsync(props20, c->mesh_props, (size_t)c->dev.count * 80, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return SPH_OK;
+}
+
+int sph_mesh_properties_device_ptr(SphContext *c, void **dptr, size_t *bytes)
+{
+    if (!c) return fail(nullptr, SPH_E_INVALID_ARG, "ctx is NULL");
+    if (!dptr) return fail(c, SPH_E_INVALID_ARG, "dptr is NULL");
+    if (!c->mesh_valid) return fail(c, SPH_E_BAD_STATE, "no mesh properties yet: call sph_update_mesh_properties first");
+    *dptr = c->mesh_props;
+    if (bytes) *bytes = (size_t)c->dev.count * 80;
     return SPH_OK;
 }
 
@@ -651,6 +694,7 @@ int sph_slab_upload(SphContext *c, uint32_t n, const float *pos4, const float *v
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->uploaded = true;
     c->grid_valid = false;
+    c->mesh_valid = false;
     c->substeps_since_upload = 0;
     c->n_ghost[0] = c->n_ghost[1] = c->n_export[0] = c->n_export[1] = 0;
     return SPH_OK;

@@ -117,6 +117,10 @@ void launch_velpos(const Dev &d, hipStream_t s);      // cur -> nxt
 // row f1: InitParticles.compute presets on the device (sph_kernels_init.hip)
 void launch_init_particles(int preset, uint32_t res, float fill, uint32_t ppd, float4 *pos4, hipStream_t s);
 
+// row f3: UpdateMeshProperties.compute (sph_kernels_mesh.hip); props = count x 5 float4, record index = particle id
+void launch_mesh_properties(const Dev &d, float low, float high, const float *scale3, const float *sim_trs16,
+                            float4 *props, hipStream_t s);
+
 // z-slab mode (sph_kernels_slab.hip)
 void launch_slab_upload(const Dev &d, uint32_t n, const float4 *pos4, const float4 *vel4, const uint32_t *ids, hipStream_t s);
 void launch_slab_classify(const Dev &d, int z_lo, int z_hi, int has_left, int has_right, float *send_l, float *send_r,

@@ -28,7 +28,8 @@ class SphFluidSimulation:
                  damFillRate: float = 0.5, viscosity: float = 0.01, restDensity: float = 1.5,
                  gasConstant: float = 150.0, stiffnessCoefficient: float = 5000.0,
                  dampingCoefficient: float = 10.0, device_id: int = 0, profile: bool = False,
-                 tiling: bool = True):
+                 tiling: bool = True, particleRadius: float = 0.01, lowSpeed: float = 0.0,
+                 highSpeed: float = 0.5):
         # inspector fields and defaults, SphFluidSimulation.cs:35-45
         self.preset = preset
         self.particleNumber = particleNumber
@@ -39,6 +40,10 @@ class SphFluidSimulation:
         self.gasConstant = gasConstant
         self.stiffnessCoefficient = stiffnessCoefficient
         self.dampingCoefficient = dampingCoefficient
+        # rendering fields :49-53 (values of SampleScene.unity:372-376), consumed by UpdateMeshProperties()
+        self.particleRadius = particleRadius
+        self.lowSpeed = lowSpeed
+        self.highSpeed = highSpeed
         self.device_id = device_id
         self.profile = profile
         self.tiling = tiling            # False: diagnostic per-target kernels (SPH_FLAG_NO_TILING)
@@ -143,6 +148,26 @@ class SphFluidSimulation:
         rho = np.empty((self.count,), np.float32)
         self._check(N.lib().sph_download(self._ctx, _fp(pos), _fp(vel), _fp(rho)))
         return pos, vel, rho
+
+    def UpdateMeshProperties(self, simTRS=None):
+        """SphFluidSimulation.cs:271-284 (row f3).  simTRS = transform.localToWorldMatrix as a 4x4 array in math
+        (row, column) notation, default identity; uses self.particleRadius / lowSpeed / highSpeed (:49-53)."""
+        m = N.SphMeshParams()
+        m.struct_size = C.sizeof(N.SphMeshParams)
+        m.low_speed = float(np.float32(self.lowSpeed))
+        m.high_speed = float(np.float32(self.highSpeed))
+        for k in range(3):
+            m.particle_scale[k] = float(np.float32(self.particleRadius))      # :280
+        trs = np.eye(4, dtype=np.float32) if simTRS is None else np.asarray(simTRS, np.float32).reshape(4, 4)
+        for k, val in enumerate(trs.T.reshape(-1)):                            # column-major like Matrix4x4
+            m.sim_trs[k] = float(val)
+        self._check(N.lib().sph_update_mesh_properties(self._ctx, C.byref(m)))
+
+    def download_mesh_properties(self) -> np.ndarray:
+        """(count, 20) float32: the _particleMeshPropertiesBuffer (:174) contents, record = texel id."""
+        props = np.empty((self.count, N.SPH_MESH_RECORD_FLOATS), np.float32)
+        self._check(N.lib().sph_download_mesh_properties(self._ctx, _fp(props)))
+        return props
 
     def step_n(self, deltaTime: float, frames: int):
         self._check(N.lib().sph_step_n(self._ctx, float(np.float32(deltaTime)), int(frames)))

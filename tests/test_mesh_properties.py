@@ -1,0 +1,142 @@
+"""Row f3: UpdateMeshProperties.compute:18-64, the render feed after the path.
+
+CPU: oracle (oracle_update_mesh_properties) vs an independent numpy restatement + hand-computed records.
+GPU: sph_update_mesh_properties / sph_download_mesh_properties == oracle on the engine's own state, bit-exact.
+No reference fixture exists for this kernel ("parity unpinned", like the rest of the oracle).
+"""
+import numpy as np
+import pytest
+
+from oracle import sph_oracle as so
+from sphfluidsimulation_amd import presets
+
+f32 = np.float32
+
+
+def _bits(a):
+    return np.ascontiguousarray(a, dtype=f32).view(np.uint32)
+
+
+def np_mesh_properties(pos, vel, low, high, scale, trs):
+    """Array-at-a-time restatement for FINITE inputs: mul(translation, scale) written out as its closed form
+    (diag(scale) with the translation in the last column), which is what the 4-term sums reduce to."""
+    pos = pos.astype(f32)
+    vel = vel.astype(f32)
+    n = pos.shape[0]
+    ss = np.array([trs[0][0], trs[1][1], trs[2][2]], f32)
+    w = pos[:, :3] * ss - ss * f32(0.5)
+    out = np.zeros((n, 20), f32)
+    out[:, 0], out[:, 5], out[:, 10], out[:, 15] = scale[0], scale[1], scale[2], 1.0
+    out[:, 12:15] = w + f32(0.0)                       # 0 + w: -0 becomes +0 as in the summed product
+    speed = np.sqrt((vel[:, 0] * vel[:, 0] + vel[:, 1] * vel[:, 1]) + vel[:, 2] * vel[:, 2])
+    with np.errstate(divide="ignore", invalid="ignore"):
+        t = (speed - f32(low)) / (f32(high) - f32(low))
+    t = np.where(np.isnan(t), f32(0), np.minimum(np.maximum(t, f32(0)), f32(1))).astype(f32)
+    out[:, 16] = t
+    out[:, 17] = 0
+    out[:, 18] = f32(1) + t * f32(-1)
+    out[:, 19] = 1
+    return out
+
+
+def test_mesh_record_by_hand():
+    pos = np.array([[0.25, 0.5, 1.0, 1.0], [0.0, 0.0, 0.0, 1.0]], f32)
+    vel = np.array([[0.3, 0.0, 0.4, 7.0], [0.0, 0.0, 0.0, 0.0]], f32)     # |v| = 0.5 (w ignored), 0
+    trs = np.diag([5.0, 3.0, 5.0, 1.0]).astype(f32)
+    trs[:3, 3] = [0.0, -1.5, 0.0]                                         # the scene's fluid-box transform; translation is unused (:38)
+    out = so.update_mesh_properties(pos, vel, 0.0, 1.0, 0.01, trs)
+    r = out[0]
+    assert r[0] == f32(0.01) and r[5] == f32(0.01) and r[10] == f32(0.01) and r[15] == 1.0
+    assert list(r[12:15]) == [f32(0.25) * f32(5) - f32(2.5), f32(0.5) * f32(3) - f32(1.5), f32(5) - f32(2.5)]
+    assert [r[k] for k in (1, 2, 3, 4, 6, 7, 8, 9, 11)] == [0.0] * 9
+    t = f32(np.sqrt(f32(f32(0.3) * f32(0.3) + f32(0.0)) + f32(0.4) * f32(0.4)))
+    assert r[16] == t and r[17] == 0.0 and r[18] == f32(1) - t and r[19] == 1.0
+    assert list(out[1][16:]) == [0.0, 0.0, 1.0, 1.0]                       # at rest: pure blue
+    assert list(out[1][12:15]) == [-2.5, -1.5, -2.5]
+
+
+@pytest.mark.parametrize("low,high", [(0.0, 0.5), (0.2, 0.2), (1.0, 0.25), (0.0, 1000.0)])
+def test_mesh_properties_two_restatements_agree_bitwise(low, high):
+    rng = np.random.default_rng(8)
+    n = 5000
+    pos = rng.uniform(0, 1, (n, 4)).astype(f32)
+    pos[:7, :3] = [[0, 0, 0], [1, 1, 1], [0.5, 0.5, 0.5], [0.5, 0, 1], [1e-30, 0.5, 0.25], [0.5, 0.5, 0], [0, 0.5, 0.5]]
+    vel = (rng.standard_normal((n, 4)) * rng.choice([0.0, 0.01, 0.3, 5.0], (n, 1))).astype(f32)
+    trs = np.diag([5.0, 3.0, 2.0, 1.0]).astype(f32)
+    scale = np.array([0.01, 0.02, 0.03], f32)
+    got = so.update_mesh_properties(pos, vel, low, high, scale, trs)
+    want = np_mesh_properties(pos, vel, low, high, scale, trs)
+    assert np.array_equal(_bits(got), _bits(want))
+    assert got[:, 16].min() >= 0.0 and got[:, 16].max() <= 1.0
+
+
+def test_mesh_properties_non_finite_position_poisons_its_row():
+    pos = np.array([[np.inf, 0.5, 0.5, 1.0], [0.5, np.nan, 0.5, 1.0]], f32)
+    vel = np.array([[np.nan, 0, 0, 0], [np.inf, 0, 0, 0]], f32)
+    out = so.update_mesh_properties(pos, vel, 0.0, 0.5, 0.01)
+    m0 = out[0, :16].reshape(4, 4).T            # back to (row, column)
+    m1 = out[1, :16].reshape(4, 4).T
+    assert np.isnan(m0[0, :3]).all() and m0[0, 3] == np.inf and not np.isnan(m0[1:]).any()   # inf * 0 = NaN, inf * 1 = inf
+    assert np.isnan(m1[1]).all() and not np.isnan(m1[[0, 2, 3]]).any()
+    assert out[0, 16] == 0.0 and out[1, 16] == 1.0                   # saturate(NaN) = 0, saturate(inf) = 1
+
+
+# ---- GPU parity ------------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("frames", [0, 2])
+def test_gpu_mesh_properties_bit_exact(frames):
+    from sphfluidsimulation_amd.simulation import SphFluidSimulation
+    n, fill = 16384, 0.8
+    R = presets.scene_bucket_resolution(n)
+    pos0, vel0 = presets.dam_break(n, fill, seed=5)
+    vel0[:, :3] = np.random.default_rng(1).standard_normal((n, 3)).astype(f32) * f32(0.2)
+    sim = SphFluidSimulation(particleNumber=n, bucketResolution=R, damFillRate=fill, particleRadius=0.013,
+                             lowSpeed=0.05, highSpeed=0.45).Start(pos0, vel0)
+    try:
+        for _ in range(frames):
+            sim.Update(1 / 60)
+        trs = np.diag([5.0, 3.0, 5.0, 1.0]).astype(f32)
+        trs[:3, 3] = [0.0, -1.5, 0.0]
+        sim.UpdateMeshProperties(trs)
+        got = sim.download_mesh_properties()
+        pos, vel, _ = sim.download()
+        want = so.update_mesh_properties(pos, vel, 0.05, 0.45, 0.013, trs)
+        assert got.shape == (n, 20)
+        assert np.array_equal(_bits(got), _bits(want))
+        if frames:
+            assert 0.0 < got[:, 16].mean() < 1.0
+    finally:
+        sim.OnDestroy()
+
+
+@pytest.mark.gpu
+def test_gpu_mesh_properties_weird_inputs_and_errors():
+    from sphfluidsimulation_amd.simulation import SphFluidSimulation
+    from sphfluidsimulation_amd import _native as N
+    import ctypes as C
+    n = 1024
+    pos0, vel0 = presets.dam_break(n, 0.8, seed=6)
+    pos0[0, :3] = [np.inf, 0.5, 0.5]
+    pos0[1, :3] = [0.5, np.nan, 0.5]
+    pos0[2, :3] = [-3.0, 7.0, 0.5]
+    vel0[3, :3] = [np.nan, 0, 0]
+    vel0[4, :3] = [np.inf, 0, 0]
+    vel0[5, :3] = [1e30, 1e30, 0]                 # |v|^2 overflows -> inf -> t = 1
+    sim = SphFluidSimulation(particleNumber=n, bucketResolution=9, damFillRate=0.8)
+    sim.Start(pos0, vel0)
+    try:
+        props = np.empty((n, 20), f32)
+        fp = props.ctypes.data_as(C.POINTER(C.c_float))
+        assert N.lib().sph_download_mesh_properties(sim._ctx, fp) == N.SPH_E_BAD_STATE   # nothing computed yet
+        sim.UpdateMeshProperties()
+        got = sim.download_mesh_properties()
+        want = so.update_mesh_properties(pos0, vel0, sim.lowSpeed, sim.highSpeed, sim.particleRadius)
+        assert np.array_equal(_bits(got), _bits(want))
+        bad = N.SphMeshParams()
+        assert N.lib().sph_update_mesh_properties(sim._ctx, C.byref(bad)) == N.SPH_E_INVALID_ARG   # struct_size 0
+        assert N.lib().sph_update_mesh_properties(sim._ctx, None) == N.SPH_E_INVALID_ARG
+        ptr, nbytes = C.c_void_p(), C.c_size_t()
+        assert N.lib().sph_mesh_properties_device_ptr(sim._ctx, C.byref(ptr), C.byref(nbytes)) == 0
+        assert ptr.value and nbytes.value == n * 80
+    finally:
+        sim.OnDestroy()
