@@ -177,6 +177,10 @@ def main():
         "render_feed": {"kernel": "k_mesh_properties", "ms": mesh_ms, "algorithmic_bytes": 112 * n,
                         "achieved_GBs": 112 * n / (mesh_ms * 1e-3) / 1e9,
                         "hbm_frac": 112 * n / (mesh_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+        "neighbour_lists": {
+            "listed_fraction_of_target_substeps": st["listed_target_substeps"] / max(n * st["launches_velpos"], 1),
+            "entries_per_listed_target": st["list_entries"] / max(st["listed_target_substeps"], 1),
+            "scanned_brick_substeps": st["scanned_brick_substeps"]},
         "max_cell_occupancy": st["max_cell_occupancy"], "nan_resets": st["nan_resets"],
         "queued_targets_last_sweep": st["queued_targets"],
     }

@@ -73,6 +73,7 @@ typedef struct SphParams {
 
 #define SPH_FLAG_PROFILE 1u     /* record HIP events around every pass (SphStats.ms_*)            */
 #define SPH_FLAG_NO_TILING 2u   /* diagnostic: per-target kernels on global memory, no LDS bricks */
+#define SPH_FLAG_NO_LISTS 4u    /* diagnostic: every sub-step re-scans its 27 bins (no frame-coherent neighbour lists) */
 
 /* Values of the uniforms the reference pushes through ShaderIDs.cs:5-32. */
 typedef struct SphDerived {
@@ -106,6 +107,10 @@ typedef struct SphStats {
     uint64_t nan_resets;         /* NaN-guard hits (VelPos.compute:143-147) since create         */
     uint64_t candidates_density; /* listed candidates visited by the last density pass (P-bar*N) */
     uint64_t halo_violations;    /* slab mode: owned targets that drifted beyond the ghost planes  */
+    /* frame-coherent neighbour lists, accumulated since the last sph_reset_stats */
+    uint64_t listed_target_substeps;  /* target sub-steps whose pair sums came from the list of sub-step 1 */
+    uint64_t scanned_brick_substeps;  /* non-empty 4x4x4 bricks that had to re-scan in a sub-step 2..S     */
+    uint64_t list_entries;            /* list entries those target sub-steps walked                        */
 } SphStats;
 
 typedef struct SphContext SphContext;

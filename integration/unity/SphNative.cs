@@ -50,6 +50,7 @@ public static class SphNative
         public ulong launches_grid, launches_density, launches_velpos;
         public uint max_cell_occupancy, overflowed_cells, dropped_particles, queued_targets;
         public ulong nan_resets, candidates_density, halo_violations;
+        public ulong listed_target_substeps, scanned_brick_substeps, list_entries;
     }
 
     [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int sph_version();

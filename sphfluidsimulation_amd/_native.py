@@ -17,6 +17,7 @@ SPH_E_UNSUPPORTED = -5
 SPH_E_COMM = -6
 SPH_FLAG_PROFILE = 1
 SPH_FLAG_NO_TILING = 2
+SPH_FLAG_NO_LISTS = 4
 SPH_SLAB_UPDATE_RHO = 0
 SPH_SLAB_UPDATE_POSVEL = 1
 SPH_SLAB_RECORD_WORDS = 9
@@ -87,6 +88,9 @@ class SphStats(C.Structure):
         ("nan_resets", C.c_uint64),
         ("candidates_density", C.c_uint64),
         ("halo_violations", C.c_uint64),
+        ("listed_target_substeps", C.c_uint64),
+        ("scanned_brick_substeps", C.c_uint64),
+        ("list_entries", C.c_uint64),
     ]
 
     def as_dict(self):

@@ -9,6 +9,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -32,6 +33,9 @@ struct SphContext {
     // staging in the reference's texture layout
     float4 *pos4_dev = nullptr, *vel4_dev = nullptr;
     float *rho_id_dev = nullptr, *pw0 = nullptr;
+    // frame-coherent neighbour lists (sph_kernels_list.hip)
+    bool nl_enabled = false, nl_allocated = false, nl_fresh = false;   // fresh: grid just built, lists not recorded yet
+    float nl_skin_frac = 0.05f;       // skin / h (profiles/: 0.04-0.06 is the optimum of the 16.7 M dam break)
     float4 *mesh_props = nullptr;     // _particleMeshPropertiesBuffer (:174), allocated on first use
     bool mesh_valid = false;
     bool uploaded = false, grid_valid = false;
@@ -128,6 +132,18 @@ static void refresh_scalars(SphContext *c)
     d.gy = p.gravity[1];
     d.gz = p.gravity[2];
     d.use_bricks = (p.flags & SPH_FLAG_NO_TILING) ? 0u : 1u;
+    // neighbour lists: skin = nl_skin_frac * h; pre-filter radius (h + skin)^2 rounded up like h2_up; a brick is calm
+    // while its relative-displacement bound stays below 90 % of the skin (the rest absorbs fp32 rounding of the bound)
+    c->nl_enabled = d.use_bricks && !c->slab && !(p.flags & SPH_FLAG_NO_LISTS) && d.R <= 256u;
+    if (const char *e = getenv("SPH_NL_SKIN")) {   // tuning aid: skin / h
+        const float v = (float)atof(e);
+        if (v > 0.0f && v <= 1.0f) c->nl_skin_frac = v;
+    }
+    {
+        const double hs = (double)d.h * (1.0 + (double)c->nl_skin_frac);
+        d.h2_list = nextafterf((float)(hs * hs * (1.0 + 1e-5)), INFINITY);
+        d.skin_ok = (float)(0.9 * (double)c->nl_skin_frac * (double)d.h);
+    }
     if (!c->slab) {
         d.zt_lo = INT_MIN;
         d.zt_hi = INT_MAX;
@@ -226,9 +242,52 @@ struct PassTimer {
 
 // ---- the three driver passes ---------------------------------------------------------------------
 
+// Buffers of the neighbour lists, on first use: 64 u32 entries + a count per particle, the binned positions, and the
+// per-brick displacement boxes.  If the device cannot hold them the engine simply keeps scanning.
+static void ensure_lists(SphContext *c)
+{
+    if (!c->nl_enabled || c->nl_allocated) return;
+    Dev &d = c->dev;
+    const size_t n = c->capacity;
+    if (n == 0 || n >= (1u << kNlSlotBits)) {
+        c->nl_enabled = false;
+        return;
+    }
+    const size_t bricks = (size_t)nl_bricks_x(d.R) * nl_bricks_y(d.R) * nl_bricks_z(d.R);
+    d.nl_cap = 64;
+    d.n_bricks = (uint32_t)bricks;
+    d.n_chunks = (uint32_t)((n + 63) / 64);
+    const size_t before = c->allocs.size();
+    const bool ok = dalloc(c, &d.p1x, n) == SPH_OK && dalloc(c, &d.p1y, n) == SPH_OK && dalloc(c, &d.p1z, n) == SPH_OK &&
+                    dalloc(c, &d.nl_ent, (size_t)d.nl_cap * ((n + 63) & ~(size_t)63)) == SPH_OK && dalloc(c, &d.nl_cnt, n) == SPH_OK &&
+                    dalloc(c, &d.chunk_box, 6 * ((n + 63) / 64)) == SPH_OK &&
+                    dalloc(c, &d.brick_rho, bricks) == SPH_OK && dalloc(c, &d.brick_state, bricks) == SPH_OK &&
+                    dalloc(c, &d.cur.p4, n) == SPH_OK && dalloc(c, &d.nxt.p4, n) == SPH_OK;
+    if (!ok) {
+        while (c->allocs.size() > before) {
+            (void)hipFree(c->allocs.back());
+            c->allocs.pop_back();
+        }
+        (void)hipGetLastError();
+        d.p1x = d.p1y = d.p1z = nullptr;
+        d.nl_ent = nullptr;
+        d.nl_cnt = nullptr;
+        d.chunk_box = d.brick_rho = nullptr;
+        d.brick_state = nullptr;
+        d.cur.p4 = d.nxt.p4 = nullptr;
+        c->nl_enabled = false;
+        c->last_error.clear();
+        return;
+    }
+    c->nl_allocated = true;
+}
+
 static int do_bucket_generation(SphContext *c)
 {
     if (!c->uploaded) return fail(c, SPH_E_BAD_STATE, "BucketGeneration before sph_upload");
+    ensure_lists(c);
+    c->dev.use_lists = c->nl_enabled && c->nl_allocated ? 1u : 0u;
+    c->nl_fresh = c->dev.use_lists != 0u;
     {
         PassTimer t(c, 0);
         launch_grid_build(c->dev, c->stream);
@@ -258,6 +317,9 @@ static int do_velpos(SphContext *c, float dt)
 {
     if (!c->grid_valid) return fail(c, SPH_E_BAD_STATE, "UpdateVelocityAndPosition before BucketGeneration");
     c->dev.dt = dt;
+    // the first sub-step after a grid build records the neighbour lists, the following ones of the frame use them
+    c->dev.nl_mode = !c->dev.use_lists ? kNlOff : (c->nl_fresh ? kNlBuild : kNlUse);
+    c->nl_fresh = false;
     {
         PassTimer t(c, 2);
         launch_velpos(c->dev, c->stream);
@@ -361,6 +423,7 @@ static int create_common(const SphParams *params, uint32_t capacity, bool slab, 
     A(dalloc(c, &d.block_sums, scan_blocks));
     A(dalloc(c, &d.queue, n));
     A(dalloc(c, &d.counters, (size_t)kCntCount));
+    A(dalloc(c, &d.stripes, (size_t)kStatCount * kStatStripes * kStatPad));
     A(dalloc(c, &c->pos4_dev, n));
     A(dalloc(c, &c->vel4_dev, n));
     A(dalloc(c, &c->rho_id_dev, n));
@@ -376,6 +439,7 @@ static int create_common(const SphParams *params, uint32_t capacity, bool slab, 
     }
 #undef A
     if (hipMemsetAsync(d.counters, 0, sizeof(unsigned long long) * kCntCount, c->stream) != hipSuccess ||
+        hipMemsetAsync(d.stripes, 0, sizeof(unsigned long long) * kStatCount * kStatStripes * kStatPad, c->stream) != hipSuccess ||
         hipMemsetAsync(d.cell_count, 0, sizeof(uint32_t) * cells, c->stream) != hipSuccess ||
         hipMemsetAsync(d.cell_start, 0, sizeof(uint32_t) * cells, c->stream) != hipSuccess ||
         hipStreamSynchronize(c->stream) != hipSuccess) {
@@ -599,6 +663,11 @@ int sph_get_stats(SphContext *c, SphStats *out)
     fold_events(c);
     unsigned long long cnt[kCntCount];
     HIP_TRY(c, hipMemcpy(cnt, c->dev.counters, sizeof cnt, hipMemcpyDeviceToHost));
+    std::vector<unsigned long long> stripes((size_t)kStatCount * kStatStripes * kStatPad);
+    HIP_TRY(c, hipMemcpy(stripes.data(), c->dev.stripes, stripes.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    unsigned long long stat[kStatCount] = {};
+    for (int k = 0; k < kStatCount; k++)
+        for (int i = 0; i < kStatStripes; i++) stat[k] += stripes[((size_t)k * kStatStripes + i) * kStatPad];
     memset(out, 0, sizeof *out);
     out->frames = c->frames;
     out->substeps = c->substeps;
@@ -614,7 +683,10 @@ int sph_get_stats(SphContext *c, SphStats *out)
     out->queued_targets = (uint32_t)cnt[kCntQueue];
     out->halo_violations = cnt[kCntHaloViolation];
     out->nan_resets = cnt[kCntNaN];
-    out->candidates_density = cnt[kCntCandidates];
+    out->candidates_density = stat[kStatCandidates];
+    out->listed_target_substeps = stat[kStatListed];
+    out->scanned_brick_substeps = cnt[kCntActiveBricks];
+    out->list_entries = stat[kStatListEntries];
     return SPH_OK;
 }
 
@@ -628,6 +700,9 @@ int sph_reset_stats(SphContext *c)
         c->ms[i] = 0;
         c->launches[i] = 0;
     }
+    HIP_TRY(c, hipMemsetAsync(c->dev.counters + kCntActiveBricks, 0, sizeof(unsigned long long), c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->dev.stripes + (size_t)kStatListed * kStatStripes * kStatPad, 0,
+                              2 * sizeof(unsigned long long) * kStatStripes * kStatPad, c->stream));
     return SPH_OK;
 }
 

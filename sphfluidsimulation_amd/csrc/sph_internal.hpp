@@ -13,6 +13,7 @@ constexpr int kWave = 64;              // CDNA4 wavefront
 struct Soa {
     float *x, *y, *z;     // position, SoA: what the neighbour scans stream (pos.w is derived, see k_download)
     float4 *rv;           // (rho, vx, vy, vz) packed: ONE 16-byte gather per in-range pair in VelPos
+    float4 *p4;           // (x, y, z, -) packed copy for the neighbour-list kernel's gathers; nullptr when lists are off
     float *vw;            // vel.w: sub-step counter / 0.003 NaN marker (VelPos.compute:146,150)
 };
 
@@ -51,11 +52,47 @@ struct Dev {
     int zt_lo, zt_hi;      // current-cell z range an owned target may reach without leaving the halo
     int zo_lo, zo_hi;      // grid planes whose particles are targets here (whole grid outside slab mode)
     unsigned long long *counters;  // device statistics, see Counter
+    unsigned long long *stripes;   // [kStatCount][kStatStripes * kStatPad]: per-wave statistics, see stat_add
+    // Frame-coherent neighbour lists (sph_kernels_list.hip): the grid is frozen for the S sub-steps of a frame, so the
+    // survivors found by sub-step 1 (radius h + skin) are the only candidates that can come into range later while the
+    // relative displacement around a brick stays below the skin.  All nullptr / 0 when the feature is off.
+    uint32_t use_lists;    // 1: sub-step 1 records lists, later sub-steps of the frame use them where still valid
+    uint32_t nl_mode;      // this launch: kNlOff, kNlBuild (first sub-step after a grid build) or kNlUse
+    float *p1x, *p1y, *p1z;  // by slot: position at grid-build time (= the bin the particle sits in for the frame)
+    uint32_t *nl_ent;      // [slot / 64][nl_cap][slot % 64]: (stencil cell 0..26) << kNlSlotBits | candidate slot, reference
+                           //   order; the lists of 64 consecutive slots interleaved: a wave reads one 256 B row per entry
+    uint16_t *nl_cnt;      // by slot: entries recorded
+    uint32_t nl_cap;
+    float *chunk_box;      // [6][chunks]: min x,y,z / max x,y,z of the displacement (cur - p1) over each 64 consecutive slots
+    uint32_t n_chunks, n_bricks;
+    uint8_t *brick_state;  // [bricks]: kBrickUnlisted (set while building), kBrickActive (set per sub-step)
+    float *brick_rho;      // [bricks]: bound on |delta_i - delta_j| around the brick, this sub-step
+    float h2_list;         // pre-filter radius^2 of the building sub-step: (h + skin)^2, rounded up
+    float skin_ok;         // a brick is calm while the relative displacement bound stays <= this
 };
+
+enum : uint32_t { kNlOff = 0, kNlBuild = 1, kNlUse = 2 };
+enum : uint8_t { kBrickUnlisted = 1, kBrickActive = 2 };
+constexpr uint32_t kNlSlotBits = 27;             // entry = cell code << 27 | slot
+constexpr int kNlBX = 4, kNlBY = 4, kNlBZ = 4;   // brick shape of the VelPos kernels (sph_kernels_brick_velpos.hip)
+
+__device__ __forceinline__ uint32_t *nl_entries(const Dev &d, uint32_t slot)   // entry e of the slot: [e * kWave]
+{
+    return d.nl_ent + ((size_t)(slot / kWave) * d.nl_cap) * kWave + (slot % kWave);
+}
+__host__ __device__ __forceinline__ uint32_t nl_bricks_x(uint32_t R) { return (R + kNlBX - 1) / kNlBX; }
+__host__ __device__ __forceinline__ uint32_t nl_bricks_y(uint32_t R) { return (R + kNlBY - 1) / kNlBY; }
+__host__ __device__ __forceinline__ uint32_t nl_bricks_z(uint32_t R) { return (R + kNlBZ - 1) / kNlBZ; }
+
+// Statistics every wave adds to (candidates visited, list entries walked): one counter would take ~0.5 M atomics on a
+// single address per launch, which alone costs milliseconds; they are spread over kStatStripes cache lines by block
+// and summed by sph_get_stats.
+enum Stat : int { kStatCandidates = 0, kStatListed, kStatListEntries, kStatCount };
+constexpr int kStatStripes = 512, kStatPad = 16;   // 16 x 8 B = one 128 B line per stripe
 
 enum Counter : int {
     kCntNaN = 0,        // NaN-guard hits
-    kCntCandidates,     // candidates visited by the density pass
+    kCntCandidates,     // (unused, see kStatCandidates)
     kCntMaxOcc,         // max cell occupancy (atomicMax)
     kCntOverflowCells,  // cells with > 32 members
     kCntDropped,        // particles whose linear cell index is outside the bucket
@@ -64,6 +101,10 @@ enum Counter : int {
     kCntWildV1,
     kCntQueue,          // length of `queue` for the pass in flight
     kCntHaloViolation,  // slab mode: owned targets whose 27 cells were not all covered by the halo
+    kCntListed,         // (unused, see kStatListed)
+    kCntActiveBricks,   // non-empty bricks that took the scanning kernel in a list-mode sub-step (since sph_reset_stats)
+    kCntListEntries,    // (unused, see kStatListEntries)
+    kCntIrregular,      // last grid build saw a position outside [0,1] (or NaN): bins say nothing about positions
     kCntCount
 };
 
@@ -112,6 +153,8 @@ void launch_download_merge(const Dev &d, const float *pw0, int substeps_done, fl
 void launch_grid_build(const Dev &d, hipStream_t s);  // keys, histogram, scan, scatter, id-sort, reorder: cur -> nxt
 void launch_density(const Dev &d, hipStream_t s);     // sph_kernels_brick.hip (tiled) + queue
 void launch_velpos(const Dev &d, hipStream_t s);      // cur -> nxt
+void launch_list_prepare(const Dev &d, hipStream_t s);  // sph_kernels_list.hip: which bricks may use their lists
+void launch_velpos_lists(const Dev &d, hipStream_t s);  // sph_kernels_list.hip: the targets of those bricks, cur -> nxt
 
 
 // row f1: InitParticles.compute presets on the device (sph_kernels_init.hip)

@@ -60,9 +60,12 @@ __global__ void __launch_bounds__(kBlock) k_cell_key_hist(Dev d)
 {
     const uint32_t p = blockIdx.x * kBlock + threadIdx.x;
     if (p >= d.count) return;
-    const uint32_t key = bucket_key(d, d.cur.x[p], d.cur.y[p], d.cur.z[p]);   // :26-29
+    const float x = d.cur.x[p], y = d.cur.y[p], z = d.cur.z[p];
+    const uint32_t key = bucket_key(d, x, y, z);                               // :26-29
     d.key[p] = key;
     atomicAdd(&d.cell_count[key], 1u);
+    if (!(x >= 0.0f && x <= 1.0f && y >= 0.0f && y <= 1.0f && z >= 0.0f && z <= 1.0f))
+        d.counters[kCntIrregular] = 1ull;                                      // only straight from an upload: VelPos clamps
 }
 
 // ---- exclusive scan of cell_count[0 .. n) -> cell_start[0 .. n], n = num_cells + 1 ------------
@@ -227,7 +230,12 @@ __global__ void __launch_bounds__(kBlock) k_reorder(Dev d)
     if (s >= d.count) return;
     const uint2 o = d.order[s];
     const uint32_t src = o.y;
-    d.nxt.x[s] = d.cur.x[src]; d.nxt.y[s] = d.cur.y[src]; d.nxt.z[s] = d.cur.z[src];
+    const float x = d.cur.x[src], y = d.cur.y[src], z = d.cur.z[src];
+    d.nxt.x[s] = x; d.nxt.y[s] = y; d.nxt.z[s] = z;
+    if (d.p1x) {                                       // neighbour lists: where the particle was when it was binned
+        d.p1x[s] = x; d.p1y[s] = y; d.p1z[s] = z;
+        d.nxt.p4[s] = make_float4(x, y, z, 0.0f);
+    }
     d.nxt.rv[s] = d.cur.rv[src];                       // the density texture persists by id
     d.nxt.vw[s] = d.cur.vw[src];
     d.id_nxt[s] = o.x;
@@ -262,6 +270,7 @@ void launch_grid_build(const Dev &d, hipStream_t s)
     uint2 *order_tmp = d.order + d.count;
     (void)hipMemsetAsync(d.cell_count, 0, sizeof(uint32_t) * (size_t)n, s);
     (void)hipMemsetAsync(d.counters + kCntMaxOcc, 0, sizeof(unsigned long long) * 3, s);
+    (void)hipMemsetAsync(d.counters + kCntIrregular, 0, sizeof(unsigned long long), s);
     hipLaunchKernelGGL(k_cell_key_hist, dim3(pb), dim3(kBlock), 0, s, d);
     hipLaunchKernelGGL(k_scan_reduce, dim3(nb), dim3(kScanThreads), 0, s, d, n);
     hipLaunchKernelGGL(k_scan_blocksums, dim3(1), dim3(kScanThreads), 0, s, d, nb);

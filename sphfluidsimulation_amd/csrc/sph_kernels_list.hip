@@ -1,0 +1,243 @@
+// Frame-coherent neighbour lists for VelPos (gfx950).
+//
+// The reference freezes the bucket for the 5 sub-steps of a frame (SphFluidSimulation.cs:98-102): every sub-step
+// walks the SAME bins, only the positions inside them have moved.  The first sub-step (k_velpos_brick<BUILD>) therefore
+// records, per target and in reference order, every listed candidate of its 27 bins with |r| < h + skin.  A later
+// sub-step of the same frame can take a target's pair sums from that list instead of re-scanning ~100 candidates,
+// and gets the reference's bits, as long as
+//   (1) no unlisted candidate of those bins can have come within h: its distance was >= h + skin and the relative
+//       displacement |delta_i - delta_j| of any pair around the target's brick is bounded by rho <= skin
+//       (k_chunk_box: per-axis displacement range of every 64 consecutive slots; k_brick_activity: merged over the
+//       slot runs that cover the brick's bins and their neighbours);
+//   (2) the target's stencil is still known: its current cell is its bin or a face/edge/corner neighbour.  Bins that
+//       left the stencil are masked per entry (the reference no longer visits them); bins that entered it were at
+//       least one cell + a beyond the target when the lists were built (a = distance to the face it crossed since),
+//       so they hold nothing within h while a >= rho.
+// Everything else -- bricks that are not calm, targets failing (2), bricks with an unlistable target -- takes the
+// scanning kernels exactly as without lists.  Out-of-range entries contribute exact zeros (VelPos.compute:37,43 and
+// the "wild" guard of sph_kernels_sweep.hip), so which path served a target does not change a bit of the result.
+#include "sph_sweep_common.hpp"
+
+namespace sph {
+
+constexpr int kBlock = 256;
+#ifndef SPH_LIST_MINWAVES
+#define SPH_LIST_MINWAVES 4
+#endif
+
+// Workgroups are dealt round-robin to the 8 XCDs (each with its own L2): give every XCD one contiguous range of the
+// slot-ordered work, so that the rows and planes a block's gathers reach are in the L2 its neighbours filled.
+__device__ __forceinline__ uint32_t xcd_contiguous_block()
+{
+    constexpr uint32_t kXcd = 8;
+    const uint32_t nb = gridDim.x, q = nb / kXcd, r = nb % kXcd;
+    const uint32_t xcd = blockIdx.x % kXcd, idx = blockIdx.x / kXcd;
+    return xcd * q + (xcd < r ? xcd : r) + idx;
+}
+
+// One wave per 64 consecutive slots: per-axis range of the displacement since the grid build.
+__global__ void __launch_bounds__(kBlock) k_chunk_box(Dev d)
+{
+    const uint32_t s = blockIdx.x * kBlock + threadIdx.x;
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    if (s < d.count) {
+        const float dl[3] = {d.cur.x[s] - d.p1x[s], d.cur.y[s] - d.p1y[s], d.cur.z[s] - d.p1z[s]};
+#pragma unroll
+        for (int a = 0; a < 3; a++) lo[a] = hi[a] = dl[a];
+    }
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+#pragma unroll
+        for (int o = kWave / 2; o > 0; o >>= 1) {
+            lo[a] = fminf(lo[a], __shfl_xor(lo[a], o, kWave));
+            hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], o, kWave));
+        }
+    const uint32_t chunk = s / kWave;
+    if ((threadIdx.x & (kWave - 1)) == 0 && chunk < d.n_chunks) {
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            d.chunk_box[(size_t)a * d.n_chunks + chunk] = lo[a];
+            d.chunk_box[(size_t)(3 + a) * d.n_chunks + chunk] = hi[a];
+        }
+    }
+}
+
+// One wave per brick, one lane per (y,z) row of the brick's bins and their neighbours (6 x 6 rows; a row of bins is
+// one run of slots): rho = bound on |delta_i - delta_j| over the 64-slot chunks those runs touch; calm <=> every target
+// of the brick has its list and rho <= skin_ok.
+__global__ void __launch_bounds__(kWave) k_brick_activity(Dev d, int nbx, int nby)
+{
+    const int b = blockIdx.x, lane = threadIdx.x, R = (int)d.R;
+    const int x0 = (b % nbx) * kNlBX, y0 = ((b / nbx) % nby) * kNlBY, z0 = (b / (nbx * nby)) * kNlBZ;
+    constexpr int kRY = kNlBY + 2, kRZ = kNlBZ + 2;
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    bool own_nonempty = false;
+    if (lane < kRY * kRZ) {
+        const int cy = y0 - 1 + lane % kRY, cz = z0 - 1 + lane / kRY;
+        if (cy >= 0 && cz >= 0 && cy < R && cz < R) {
+            const int xa = x0 - 1 > 0 ? x0 - 1 : 0, xb = x0 + kNlBX < R - 1 ? x0 + kNlBX : R - 1;   // bins xa..xb
+            const uint32_t rk = (uint32_t)cy * d.R + (uint32_t)cz * d.R * d.R;
+            const uint32_t s0 = d.cell_start[rk + (uint32_t)xa], s1 = d.cell_start[rk + (uint32_t)xb + 1u];
+            if (s1 > s0) {
+                own_nonempty = cy >= y0 && cy < y0 + kNlBY && cz >= z0 && cz < z0 + kNlBZ;   // (approximately: the row)
+                for (uint32_t c = s0 / kWave; c <= (s1 - 1) / kWave; c++)
+#pragma unroll
+                    for (int a = 0; a < 3; a++) {
+                        lo[a] = fminf(lo[a], d.chunk_box[(size_t)a * d.n_chunks + c]);
+                        hi[a] = fmaxf(hi[a], d.chunk_box[(size_t)(3 + a) * d.n_chunks + c]);
+                    }
+            }
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+#pragma unroll
+        for (int o = kWave / 2; o > 0; o >>= 1) {
+            lo[a] = fminf(lo[a], __shfl_xor(lo[a], o, kWave));
+            hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], o, kWave));
+        }
+    const bool nonempty = __any(own_nonempty);
+    if (lane == 0) {
+        float r2 = 0.0f;
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            const float r = hi[a] >= lo[a] ? hi[a] - lo[a] : 0.0f;   // empty neighbourhood: nothing moved
+            r2 += r * r;
+        }
+        const float rho = sqrtf(r2) * 1.00001f;
+        const uint8_t st = d.brick_state[b] & kBrickUnlisted;
+        const bool active = st != 0 || !(rho <= d.skin_ok);          // NaN-safe
+        d.brick_state[b] = st | (active ? kBrickActive : 0);
+        d.brick_rho[b] = rho;
+        if (active && nonempty) atomicAdd(&d.counters[kCntActiveBricks], 1ull);
+    }
+}
+
+// Hands the flagged targets of a block to the generic queue with ONE atomic on the queue counter (every thread of the
+// block must call it).  ~1 % of the targets fail condition (2) in a sub-step, i.e. nearly every wave holds one: an
+// atomic per lane, or even per wave, on that single address would serialise the launch (~3 ns each).
+__device__ __forceinline__ void enqueue_block(const Dev &d, bool pred, uint32_t slot, uint32_t *s_cnt)
+{
+    if (threadIdx.x == 0) s_cnt[0] = 0;
+    __syncthreads();
+    uint32_t k = 0;
+    if (pred) k = atomicAdd(&s_cnt[0], 1u);
+    __syncthreads();
+    if (threadIdx.x == 0 && s_cnt[0]) s_cnt[1] = (uint32_t)atomicAdd(&d.counters[kCntQueue], (unsigned long long)s_cnt[0]);
+    __syncthreads();
+    if (pred) d.queue[s_cnt[1] + k] = slot;
+}
+
+// VelPos.compute:46-158 for the targets of CALM bricks, one lane per slot: pair sums from the list recorded by the
+// frame's first sub-step.  Slot order keeps every per-target stream (9 loads, 6 stores, the 256 B entry rows) fully
+// coalesced; the candidates of 64 consecutive slots (~17 bins of one row and their neighbours, ~20 KB of
+// (x,y,z,-) + (rho,vx,vy,vz)) are gathered through L1/L2 -- there is no tile to stage.  The pair arithmetic
+// (~160 VALU instructions per entry, 14 IEEE divisions per two entries) is what bounds the kernel.
+__global__ void __launch_bounds__(kBlock, SPH_LIST_MINWAVES) k_velpos_list(Dev d)
+{
+    __shared__ uint32_t s_queue[2];
+    if (nl_blocked(d)) return;                     // the scanning kernels take everything
+    const uint32_t s_raw = xcd_contiguous_block() * kBlock + threadIdx.x;
+    bool live = s_raw < d.count;
+    const uint32_t s = live ? s_raw : 0u;
+    const int R = (int)d.R;
+    const float qx = d.p1x[s], qy = d.p1y[s], qz = d.p1z[s];                     // where it was binned
+    const float pix = d.cur.x[s], piy = d.cur.y[s], piz = d.cur.z[s];            // :57
+    const float4 rvi = d.cur.rv[s];
+    const float viw = d.cur.vw[s];
+    uint32_t n = d.nl_cnt[s];
+    const uint32_t key = bucket_key(d, qx, qy, qz);                              // the bin, Bucket.compute:26-29
+    live = live && key < d.num_cells;                                            // limbo: queued by the brick kernel
+    const uint32_t brick = live ? nl_brick_of_key(d, key) : 0u;
+    live = live && !(d.brick_state[brick] & kBrickActive);                       // else the scanning kernel takes it
+    // the stencil now (:58) against the stencil the list was recorded for
+    const int c0x = cell_coord(qx, d.Rm1, R), c0y = cell_coord(qy, d.Rm1, R), c0z = cell_coord(qz, d.Rm1, R);
+    const int shx = cell_coord(pix, d.Rm1, R) - c0x, shy = cell_coord(piy, d.Rm1, R) - c0y,
+              shz = cell_coord(piz, d.Rm1, R) - c0z;
+    uint32_t mask = 0x7FFFFFFu;                    // recorded stencil cells that are still in the stencil
+    bool hand_over = false;
+    if (live && (shx | shy | shz) != 0) {
+        // condition (2): at most one cell away, and deeper than rho behind every face crossed since the lists were built
+        const float need = d.brick_rho[brick] * d.Rm1 * 1.0001f + 1e-4f;         // cell units + fp slack
+        const float ux = qx * d.Rm1, uy = qy * d.Rm1, uz = qz * d.Rm1;
+        bool ok = shx >= -1 && shx <= 1 && shy >= -1 && shy <= 1 && shz >= -1 && shz <= 1;
+        if (shx > 0) ok = ok && ((float)(c0x + 1) - ux >= need);
+        if (shx < 0) ok = ok && (ux - (float)c0x >= need);
+        if (shy > 0) ok = ok && ((float)(c0y + 1) - uy >= need);
+        if (shy < 0) ok = ok && (uy - (float)c0y >= need);
+        if (shz > 0) ok = ok && ((float)(c0z + 1) - uz >= need);
+        if (shz < 0) ok = ok && (uz - (float)c0z >= need);
+        if (!ok) {
+            hand_over = true;                      // the generic per-target kernel scans for this one
+            live = false;
+        } else {
+            // offsets {-1,0,1} of the recorded stencil within one cell of the shifted centre, per axis
+            const uint32_t ax = shx > 0 ? 6u : (shx < 0 ? 3u : 7u), ay = shy > 0 ? 6u : (shy < 0 ? 3u : 7u),
+                           az = shz > 0 ? 6u : (shz < 0 ? 3u : 7u);
+            mask = 0;
+#pragma unroll
+            for (int code = 0; code < 27; code++)
+                if (((ax >> (code / 9)) & (ay >> ((code / 3) % 3)) & (az >> (code % 3))) & 1u) mask |= 1u << code;
+        }
+    }
+    enqueue_block(d, hand_over, s, s_queue);
+    const float rho_i = rvi.x;                                                   // :60
+    const float p_i = d.gas_const * (rho_i - d.rest_density);                    // :61
+    const float vix = rvi.y, viy = rvi.z, viz = rvi.w;                           // :62
+    Force f{0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};                                 // :64-65
+    if (!live) n = 0;
+
+    struct Cand {
+        float x, y, z, rho, vx, vy, vz;
+        bool take;
+    };
+    const uint32_t slot_mask = (1u << kNlSlotBits) - 1u;
+    const uint32_t *ent = nl_entries(d, s);
+    auto word = [&](uint32_t e) { return ent[(e < n ? e : n - 1) * kWave]; };    // one coalesced 256 B row per wave
+    auto gather = [&](uint32_t w) {
+        const uint32_t j = w & slot_mask;
+        const float4 pj = d.cur.p4[j];
+        const float4 rv = d.cur.rv[j];                                           // :86, :94
+        return Cand{pj.x, pj.y, pj.z, rv.x, rv.y, rv.z, rv.w,
+                    j != s && ((mask >> (w >> kNlSlotBits)) & 1u) != 0u};        // :82 and the stencil test :73
+    };
+#if defined(SPH_ABLATE) && SPH_ABLATE >= 5   /* diagnostic: no entry loop */
+    if (false) {
+#else
+    if (n) {
+#endif
+        // two entries per trip; the entry words run two trips ahead of the arithmetic, their gathers one trip
+        uint32_t w2 = word(2), w3 = word(3);
+        Cand a0 = gather(word(0)), a1 = gather(word(1));
+        for (uint32_t e = 0; e < n; e += 2) {
+            const Cand b0 = gather(w2), b1 = gather(w3);
+            w2 = word(e + 4);
+            w3 = word(e + 5);
+            pair_force_vals(d, pix - a0.x, piy - a0.y, piz - a0.z, a0.rho, a0.vx, a0.vy, a0.vz, vix, viy, viz, p_i, f,
+                            a0.take);                                            // :86-95
+            pair_force_vals(d, pix - a1.x, piy - a1.y, piz - a1.z, a1.rho, a1.vx, a1.vy, a1.vz, vix, viy, viz, p_i, f,
+                            e + 1 < n && a1.take);
+            a0 = b0;
+            a1 = b1;
+        }
+    }
+    if (live) integrate_store(d, s, pix, piy, piz, vix, viy, viz, viw, rho_i, f);  // :100-157
+    stat_add(d, kStatListed, live ? 1ull : 0ull);
+    stat_add(d, kStatListEntries, (unsigned long long)n);
+}
+
+static inline uint32_t cdiv(uint32_t a, uint32_t b) { return a ? (a + b - 1) / b : 1u; }
+
+void launch_list_prepare(const Dev &d, hipStream_t s)
+{
+    const uint32_t nbx = nl_bricks_x(d.R), nby = nl_bricks_y(d.R), nbz = nl_bricks_z(d.R);
+    hipLaunchKernelGGL(k_chunk_box, dim3(cdiv(d.count, kBlock)), dim3(kBlock), 0, s, d);
+    hipLaunchKernelGGL(k_brick_activity, dim3(nbx * nby * nbz), dim3(kWave), 0, s, d, (int)nbx, (int)nby);
+}
+
+void launch_velpos_lists(const Dev &d, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_velpos_list, dim3(cdiv(d.count, kBlock)), dim3(kBlock), 0, s, d);
+}
+
+}  // namespace sph

@@ -118,8 +118,7 @@ __global__ void __launch_bounds__(kBlock) k_density_exact(Dev d)
     const uint32_t s = blockIdx.x * kBlock + threadIdx.x;
     unsigned long long v = 0;
     if (s < d.count && !(d.ghost && d.ghost[s])) v = density_target(d, s);
-    v = wave_sum_u64(v);
-    if ((threadIdx.x & (kWave - 1)) == 0 && v) atomicAdd(&d.counters[kCntCandidates], v);
+    stat_add(d, kStatCandidates, v);
 }
 
 __global__ void __launch_bounds__(kBlock) k_velpos_exact(Dev d)
@@ -142,8 +141,7 @@ __global__ void __launch_bounds__(kBlock) k_density_queue(Dev d)
         const uint32_t q = q0 + threadIdx.x;
         if (q < qlen && !(d.ghost && d.ghost[d.queue[q]])) v += density_target(d, d.queue[q]);
     }
-    v = wave_sum_u64(v);
-    if ((threadIdx.x & (kWave - 1)) == 0 && v) atomicAdd(&d.counters[kCntCandidates], v);
+    stat_add(d, kStatCandidates, v);
 }
 
 __global__ void __launch_bounds__(kBlock) k_velpos_queue(Dev d)

@@ -88,8 +88,12 @@ __device__ __forceinline__ void pair_force(const Dev &d, uint32_t j, float pix, 
                     viz, p_i, f);                                                // :86-89
 }
 
-// VelPos.compute:100-157: scaling, wall force, NaN guard, integrate, clamp, store.
-__device__ __forceinline__ void integrate_store(const Dev &d, uint32_t s, float pix, float piy, float piz,
+struct Pos3 {
+    float x, y, z;
+};
+
+// VelPos.compute:100-157: scaling, wall force, NaN guard, integrate, clamp, store.  Returns the new position.
+__device__ __forceinline__ Pos3 integrate_store(const Dev &d, uint32_t s, float pix, float piy, float piz,
                                                 float vix, float viy, float viz, float viw, float rho_i,
                                                 Force f)
 {
@@ -133,12 +137,29 @@ __device__ __forceinline__ void integrate_store(const Dev &d, uint32_t s, float 
         voz = viz + az * d.dt;
         vow = viw + 1.0f;
     }
-    d.nxt.x[s] = clamp01(pix + d.dt * vox);                                      // :153-154
-    d.nxt.y[s] = clamp01(piy + d.dt * voy);
-    d.nxt.z[s] = clamp01(piz + d.dt * voz);
+    const Pos3 pn{clamp01(pix + d.dt * vox), clamp01(piy + d.dt * voy), clamp01(piz + d.dt * voz)};  // :153-154
+#if defined(SPH_ABLATE) && SPH_ABLATE == 11
+    d.nxt.vw[s] = pn.x + pn.y + pn.z + vox + voy + voz + vow;
+#elif defined(SPH_ABLATE) && SPH_ABLATE == 12
+    d.nxt.rv[s] = make_float4(rho_i, vox, voy, voz);
+    d.nxt.vw[s] = pn.x + pn.y + pn.z + vow;
+#else
+    d.nxt.x[s] = pn.x;
+    d.nxt.y[s] = pn.y;
+    d.nxt.z[s] = pn.z;
+    if (d.nxt.p4) d.nxt.p4[s] = make_float4(pn.x, pn.y, pn.z, 0.0f);
     d.nxt.rv[s] = make_float4(rho_i, vox, voy, voz);                             // :156 (+ rho rides along)
     d.nxt.vw[s] = vow;
+#endif
     if (is_wild(vox) || is_wild(voy) || is_wild(voz)) d.counters[kCntWildV0 + (d.wild_v_cur ^ 1)] = 1ull;
+    return pn;
+}
+
+// brick of a bin (row-major bricks of kNlBX x kNlBY x kNlBZ bins, as the VelPos brick kernels number them)
+__device__ __forceinline__ uint32_t nl_brick_of_key(const Dev &d, uint32_t key)
+{
+    const uint32_t bx = key % d.R, by = (key / d.R) % d.R, bz = key / (d.R * d.R);
+    return bx / kNlBX + nl_bricks_x(d.R) * (by / kNlBY + nl_bricks_y(d.R) * (bz / kNlBZ));
 }
 
 __device__ __forceinline__ bool launch_is_wild(const Dev &d)
@@ -146,11 +167,26 @@ __device__ __forceinline__ bool launch_is_wild(const Dev &d)
     return d.force_slow != 0u || d.counters[kCntWildP] != 0ull || d.counters[kCntWildV0 + d.wild_v_cur] != 0ull;
 }
 
+// Neighbour lists may not be used for this launch: wild values need the literal loop, and after a grid build that saw
+// positions outside the unit box a bin says nothing about where its members are (sph_kernels_list.hip, condition 2).
+__device__ __forceinline__ bool nl_blocked(const Dev &d)
+{
+    return launch_is_wild(d) || d.counters[kCntIrregular] != 0ull;
+}
+
 __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
 {
 #pragma unroll
     for (int o = kWave / 2; o > 0; o >>= 1) v += __shfl_down(v, o, kWave);
     return v;
+}
+
+// wave total of `v` into the block's stripe of statistic `stat` (every lane of the wave must call it)
+__device__ __forceinline__ void stat_add(const Dev &d, int stat, unsigned long long v)
+{
+    v = wave_sum_u64(v);
+    if ((threadIdx.x & (kWave - 1)) == 0 && v)
+        atomicAdd(&d.stripes[((size_t)stat * kStatStripes + (blockIdx.x % kStatStripes)) * kStatPad], v);
 }
 
 }  // namespace sph
