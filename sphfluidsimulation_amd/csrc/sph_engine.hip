@@ -34,7 +34,9 @@ struct SphContext {
     float4 *pos4_dev = nullptr, *vel4_dev = nullptr;
     float *rho_id_dev = nullptr, *pw0 = nullptr;
     // frame-coherent neighbour lists (sph_kernels_list.hip)
-    bool nl_enabled = false, nl_allocated = false, nl_fresh = false;   // fresh: grid just built, lists not recorded yet
+    bool nl_enabled = false, nl_allocated = false;
+    bool nl_fresh = false;            // the grid was just built: the next density pass runs on the binned positions
+    bool nl_recorded = false;         // ... and recorded the lists the VelPos sub-steps of this frame may use
     float nl_skin_frac = 0.05f;       // skin / h (profiles/: 0.04-0.06 is the optimum of the 16.7 M dam break)
     float4 *mesh_props = nullptr;     // _particleMeshPropertiesBuffer (:174), allocated on first use
     bool mesh_valid = false;
@@ -261,7 +263,7 @@ static void ensure_lists(SphContext *c)
     const bool ok = dalloc(c, &d.p1x, n) == SPH_OK && dalloc(c, &d.p1y, n) == SPH_OK && dalloc(c, &d.p1z, n) == SPH_OK &&
                     dalloc(c, &d.nl_ent, (size_t)d.nl_cap * ((n + 63) & ~(size_t)63)) == SPH_OK && dalloc(c, &d.nl_cnt, n) == SPH_OK &&
                     dalloc(c, &d.chunk_box, 6 * ((n + 63) / 64)) == SPH_OK &&
-                    dalloc(c, &d.brick_rho, bricks) == SPH_OK && dalloc(c, &d.brick_state, bricks) == SPH_OK &&
+                    dalloc(c, &d.brick_rho, 3 * bricks) == SPH_OK && dalloc(c, &d.active_list, bricks) == SPH_OK && dalloc(c, &d.brick_state, bricks) == SPH_OK &&
                     dalloc(c, &d.cur.p4, n) == SPH_OK && dalloc(c, &d.nxt.p4, n) == SPH_OK;
     if (!ok) {
         while (c->allocs.size() > before) {
@@ -273,6 +275,7 @@ static void ensure_lists(SphContext *c)
         d.nl_ent = nullptr;
         d.nl_cnt = nullptr;
         d.chunk_box = d.brick_rho = nullptr;
+        d.active_list = nullptr;
         d.brick_state = nullptr;
         d.cur.p4 = d.nxt.p4 = nullptr;
         c->nl_enabled = false;
@@ -288,6 +291,7 @@ static int do_bucket_generation(SphContext *c)
     ensure_lists(c);
     c->dev.use_lists = c->nl_enabled && c->nl_allocated ? 1u : 0u;
     c->nl_fresh = c->dev.use_lists != 0u;
+    c->nl_recorded = false;
     {
         PassTimer t(c, 0);
         launch_grid_build(c->dev, c->stream);
@@ -304,10 +308,13 @@ static int do_bucket_generation(SphContext *c)
 static int do_density(SphContext *c)
 {
     if (!c->grid_valid) return fail(c, SPH_E_BAD_STATE, "DensityCalculation before BucketGeneration");
+    // the density pass of a fresh grid sees every particle where it was binned: it records the neighbour lists
+    c->dev.nl_mode = c->nl_fresh ? kNlBuild : kNlOff;
     {
         PassTimer t(c, 1);
         launch_density(c->dev, c->stream);
     }
+    if (c->nl_fresh) c->nl_recorded = true;
     HIP_TRY(c, hipGetLastError());
     c->dev.force_slow = 0;  // the pressure flag now matches the current gas_const / rest_density
     return SPH_OK;
@@ -317,9 +324,8 @@ static int do_velpos(SphContext *c, float dt)
 {
     if (!c->grid_valid) return fail(c, SPH_E_BAD_STATE, "UpdateVelocityAndPosition before BucketGeneration");
     c->dev.dt = dt;
-    // the first sub-step after a grid build records the neighbour lists, the following ones of the frame use them
-    c->dev.nl_mode = !c->dev.use_lists ? kNlOff : (c->nl_fresh ? kNlBuild : kNlUse);
-    c->nl_fresh = false;
+    c->dev.nl_mode = c->dev.use_lists && c->nl_recorded ? kNlUse : kNlOff;
+    c->nl_fresh = false;              // positions move: a later density pass of this frame must not record
     {
         PassTimer t(c, 2);
         launch_velpos(c->dev, c->stream);

@@ -65,8 +65,9 @@ struct Dev {
     uint32_t nl_cap;
     float *chunk_box;      // [6][chunks]: min x,y,z / max x,y,z of the displacement (cur - p1) over each 64 consecutive slots
     uint32_t n_chunks, n_bricks;
+    uint32_t *active_list; // [bricks]: the bricks the scanning kernel must take this sub-step (kNlUse)
     uint8_t *brick_state;  // [bricks]: kBrickUnlisted (set while building), kBrickActive (set per sub-step)
-    float *brick_rho;      // [bricks]: bound on |delta_i - delta_j| around the brick, this sub-step
+    float *brick_rho;      // [3][bricks]: per-axis bound on |delta_i - delta_j| around the brick, this sub-step
     float h2_list;         // pre-filter radius^2 of the building sub-step: (h + skin)^2, rounded up
     float skin_ok;         // a brick is calm while the relative displacement bound stays <= this
 };
@@ -104,6 +105,7 @@ enum Counter : int {
     kCntListed,         // (unused, see kStatListed)
     kCntActiveBricks,   // non-empty bricks that took the scanning kernel in a list-mode sub-step (since sph_reset_stats)
     kCntListEntries,    // (unused, see kStatListEntries)
+    kCntActiveCount,    // length of active_list for the sub-step in flight
     kCntIrregular,      // last grid build saw a position outside [0,1] (or NaN): bins say nothing about positions
     kCntCount
 };

@@ -10,9 +10,10 @@
 //       (k_chunk_box: per-axis displacement range of every 64 consecutive slots; k_brick_activity: merged over the
 //       slot runs that cover the brick's bins and their neighbours);
 //   (2) the target's stencil is still known: its current cell is its bin or a face/edge/corner neighbour.  Bins that
-//       left the stencil are masked per entry (the reference no longer visits them); bins that entered it were at
-//       least one cell + a beyond the target when the lists were built (a = distance to the face it crossed since),
-//       so they hold nothing within h while a >= rho.
+//       left the stencil are masked per entry (the reference no longer visits them); a bin that entered it lies beyond
+//       a face the target crossed since, along that axis at least one cell + a from where the target was when the
+//       lists were built (a = its distance to that face then), so it holds nothing within h = one cell while a is at
+//       least the range of the displacements along that axis (two cells around the brick).
 // Everything else -- bricks that are not calm, targets failing (2), bricks with an unlistable target -- takes the
 // scanning kernels exactly as without lists.  Out-of-range entries contribute exact zeros (VelPos.compute:37,43 and
 // the "wild" guard of sph_kernels_sweep.hip), so which path served a target does not change a bit of the result.
@@ -62,24 +63,33 @@ __global__ void __launch_bounds__(kBlock) k_chunk_box(Dev d)
     }
 }
 
-// One wave per brick, one lane per (y,z) row of the brick's bins and their neighbours (6 x 6 rows; a row of bins is
-// one run of slots): rho = bound on |delta_i - delta_j| over the 64-slot chunks those runs touch; calm <=> every target
-// of the brick has its list and rho <= skin_ok.
-__global__ void __launch_bounds__(kWave) k_brick_activity(Dev d, int nbx, int nby)
+// One wave per brick (4 bricks per block), one lane per (y,z) row of the bins within TWO cells of the brick's bins
+// (8 x 8 rows; a row of bins is one run of slots): the per-axis ranges of the displacement over the 64-slot chunks those
+// runs touch bound |delta_i - delta_j| for a target i of the brick and any j in its recorded stencil (one cell away,
+// condition 1) or in a bin that may enter its stencil (two cells away, condition 2).
+// calm <=> every target of the brick has its list and the Euclidean bound rho <= skin_ok.
+__global__ void __launch_bounds__(kBlock) k_brick_activity(Dev d, int nbx, int nby, int n_bricks)
 {
-    const int b = blockIdx.x, lane = threadIdx.x, R = (int)d.R;
+    __shared__ uint32_t s_act[2];
+    const int b_raw = blockIdx.x * (kBlock / kWave) + threadIdx.x / kWave, lane = threadIdx.x & (kWave - 1), R = (int)d.R;
+    const bool exists = b_raw < n_bricks;          // wave-uniform
+    const int b = exists ? b_raw : n_bricks - 1;
+    const bool blocked = nl_blocked(d);            // then the scanning kernel takes every brick
+    if (threadIdx.x == 0) s_act[0] = 0;
+    __syncthreads();
     const int x0 = (b % nbx) * kNlBX, y0 = ((b / nbx) % nby) * kNlBY, z0 = (b / (nbx * nby)) * kNlBZ;
-    constexpr int kRY = kNlBY + 2, kRZ = kNlBZ + 2;
+    constexpr int kRY = kNlBY + 4, kRZ = kNlBZ + 4;
+    static_assert(kRY * kRZ <= kWave, "one lane per row");
     float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
     bool own_nonempty = false;
     if (lane < kRY * kRZ) {
-        const int cy = y0 - 1 + lane % kRY, cz = z0 - 1 + lane / kRY;
+        const int cy = y0 - 2 + lane % kRY, cz = z0 - 2 + lane / kRY;
         if (cy >= 0 && cz >= 0 && cy < R && cz < R) {
-            const int xa = x0 - 1 > 0 ? x0 - 1 : 0, xb = x0 + kNlBX < R - 1 ? x0 + kNlBX : R - 1;   // bins xa..xb
+            const int xa = x0 - 2 > 0 ? x0 - 2 : 0, xb = x0 + kNlBX + 1 < R - 1 ? x0 + kNlBX + 1 : R - 1;   // bins xa..xb
             const uint32_t rk = (uint32_t)cy * d.R + (uint32_t)cz * d.R * d.R;
             const uint32_t s0 = d.cell_start[rk + (uint32_t)xa], s1 = d.cell_start[rk + (uint32_t)xb + 1u];
             if (s1 > s0) {
-                own_nonempty = cy >= y0 && cy < y0 + kNlBY && cz >= z0 && cz < z0 + kNlBZ;   // (approximately: the row)
+                own_nonempty = cy >= y0 && cy < y0 + kNlBY && cz >= z0 && cz < z0 + kNlBZ;   // (roughly: the row)
                 for (uint32_t c = s0 / kWave; c <= (s1 - 1) / kWave; c++)
 #pragma unroll
                     for (int a = 0; a < 3; a++) {
@@ -97,20 +107,27 @@ __global__ void __launch_bounds__(kWave) k_brick_activity(Dev d, int nbx, int nb
             hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], o, kWave));
         }
     const bool nonempty = __any(own_nonempty);
-    if (lane == 0) {
-        float r2 = 0.0f;
+    uint32_t my_pos = 0xFFFFFFFFu;
+    if (lane == 0 && exists) {
+        float r2 = 0.0f, r[3];
 #pragma unroll
         for (int a = 0; a < 3; a++) {
-            const float r = hi[a] >= lo[a] ? hi[a] - lo[a] : 0.0f;   // empty neighbourhood: nothing moved
-            r2 += r * r;
+            r[a] = (hi[a] >= lo[a] ? hi[a] - lo[a] : 0.0f) * 1.00001f;   // empty neighbourhood: nothing moved
+            r2 += r[a] * r[a];
+            d.brick_rho[(size_t)a * d.n_bricks + b] = r[a];              // per axis: what condition (2) compares with
         }
         const float rho = sqrtf(r2) * 1.00001f;
         const uint8_t st = d.brick_state[b] & kBrickUnlisted;
-        const bool active = st != 0 || !(rho <= d.skin_ok);          // NaN-safe
+        const bool active = blocked || st != 0 || !(rho <= d.skin_ok);   // NaN-safe
         d.brick_state[b] = st | (active ? kBrickActive : 0);
-        d.brick_rho[b] = rho;
-        if (active && nonempty) atomicAdd(&d.counters[kCntActiveBricks], 1ull);
+        if (active && nonempty && !blocked) atomicAdd(&d.counters[kCntActiveBricks], 1ull);
+        if (active) my_pos = atomicAdd(&s_act[0], 1u);
     }
+    // the block's active bricks go to the work list of the scanning kernel with one atomic
+    __syncthreads();
+    if (threadIdx.x == 0 && s_act[0]) s_act[1] = (uint32_t)atomicAdd(&d.counters[kCntActiveCount], (unsigned long long)s_act[0]);
+    __syncthreads();
+    if (my_pos != 0xFFFFFFFFu) d.active_list[s_act[1] + my_pos] = (uint32_t)b;
 }
 
 // Hands the flagged targets of a block to the generic queue with ONE atomic on the queue counter (every thread of the
@@ -157,16 +174,20 @@ __global__ void __launch_bounds__(kBlock, SPH_LIST_MINWAVES) k_velpos_list(Dev d
     uint32_t mask = 0x7FFFFFFu;                    // recorded stencil cells that are still in the stencil
     bool hand_over = false;
     if (live && (shx | shy | shz) != 0) {
-        // condition (2): at most one cell away, and deeper than rho behind every face crossed since the lists were built
-        const float need = d.brick_rho[brick] * d.Rm1 * 1.0001f + 1e-4f;         // cell units + fp slack
+        // condition (2): at most one cell away, and -- along every axis it crossed a face of -- deeper behind that face
+        // when the lists were built than any two particles around the brick have moved apart along that axis since
+        // (cell units; the constants absorb the fp32 rounding of u and of the ranges)
+        const float nx = d.brick_rho[brick] * d.Rm1 * 1.0001f + 1e-4f,
+                    ny = d.brick_rho[(size_t)d.n_bricks + brick] * d.Rm1 * 1.0001f + 1e-4f,
+                    nz = d.brick_rho[2 * (size_t)d.n_bricks + brick] * d.Rm1 * 1.0001f + 1e-4f;
         const float ux = qx * d.Rm1, uy = qy * d.Rm1, uz = qz * d.Rm1;
         bool ok = shx >= -1 && shx <= 1 && shy >= -1 && shy <= 1 && shz >= -1 && shz <= 1;
-        if (shx > 0) ok = ok && ((float)(c0x + 1) - ux >= need);
-        if (shx < 0) ok = ok && (ux - (float)c0x >= need);
-        if (shy > 0) ok = ok && ((float)(c0y + 1) - uy >= need);
-        if (shy < 0) ok = ok && (uy - (float)c0y >= need);
-        if (shz > 0) ok = ok && ((float)(c0z + 1) - uz >= need);
-        if (shz < 0) ok = ok && (uz - (float)c0z >= need);
+        if (shx > 0) ok = ok && ((float)(c0x + 1) - ux >= nx);
+        if (shx < 0) ok = ok && (ux - (float)c0x >= nx);
+        if (shy > 0) ok = ok && ((float)(c0y + 1) - uy >= ny);
+        if (shy < 0) ok = ok && (uy - (float)c0y >= ny);
+        if (shz > 0) ok = ok && ((float)(c0z + 1) - uz >= nz);
+        if (shz < 0) ok = ok && (uz - (float)c0z >= nz);
         if (!ok) {
             hand_over = true;                      // the generic per-target kernel scans for this one
             live = false;
@@ -231,8 +252,10 @@ static inline uint32_t cdiv(uint32_t a, uint32_t b) { return a ? (a + b - 1) / b
 void launch_list_prepare(const Dev &d, hipStream_t s)
 {
     const uint32_t nbx = nl_bricks_x(d.R), nby = nl_bricks_y(d.R), nbz = nl_bricks_z(d.R);
+    (void)hipMemsetAsync(d.counters + kCntActiveCount, 0, sizeof(unsigned long long), s);
     hipLaunchKernelGGL(k_chunk_box, dim3(cdiv(d.count, kBlock)), dim3(kBlock), 0, s, d);
-    hipLaunchKernelGGL(k_brick_activity, dim3(nbx * nby * nbz), dim3(kWave), 0, s, d, (int)nbx, (int)nby);
+    hipLaunchKernelGGL(k_brick_activity, dim3(cdiv(nbx * nby * nbz, kBlock / kWave)), dim3(kBlock), 0, s, d, (int)nbx,
+                       (int)nby, (int)(nbx * nby * nbz));
 }
 
 void launch_velpos_lists(const Dev &d, hipStream_t s)

@@ -31,13 +31,16 @@ __device__ __forceinline__ CellRange cell_range(const Dev &d, int jx, int jy, in
     return r;
 }
 
-// Density.compute:22-27 W() times _ParticleMass (:54)
-__device__ __forceinline__ float density_term(const Dev &d, float rx, float ry, float rz)
+// Density.compute:22-27 W() times _ParticleMass (:54), from abs_r2 = (rx*rx + ry*ry) + rz*rz (:24)
+__device__ __forceinline__ float density_term_r2(const Dev &d, float abs_r2)
 {
-    const float abs_r2 = (rx * rx + ry * ry) + rz * rz;                          // :24
     const float diff_r2 = d.h2 - abs_r2;                                         // :25
     const float w = 0.0f < diff_r2 ? d.c_poly6 * ((diff_r2 * diff_r2) * diff_r2) / d.h9 : 0.0f; // :26
     return d.mass * w;                                                           // :54
+}
+__device__ __forceinline__ float density_term(const Dev &d, float rx, float ry, float rz)
+{
+    return density_term_r2(d, (rx * rx + ry * ry) + rz * rz);                    // :24
 }
 
 struct Force {
