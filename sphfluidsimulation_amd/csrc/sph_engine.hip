@@ -325,6 +325,7 @@ static int do_velpos(SphContext *c, float dt)
     if (!c->grid_valid) return fail(c, SPH_E_BAD_STATE, "UpdateVelocityAndPosition before BucketGeneration");
     c->dev.dt = dt;
     c->dev.nl_mode = c->dev.use_lists && c->nl_recorded ? kNlUse : kNlOff;
+    c->dev.nl_still = c->nl_fresh ? 1u : 0u;   // first sub-step since the grid build: the recorded positions still stand
     c->nl_fresh = false;              // positions move: a later density pass of this frame must not record
     {
         PassTimer t(c, 2);

@@ -57,7 +57,8 @@ struct Dev {
     // survivors found by sub-step 1 (radius h + skin) are the only candidates that can come into range later while the
     // relative displacement around a brick stays below the skin.  All nullptr / 0 when the feature is off.
     uint32_t use_lists;    // 1: sub-step 1 records lists, later sub-steps of the frame use them where still valid
-    uint32_t nl_mode;      // this launch: kNlOff, kNlBuild (first sub-step after a grid build) or kNlUse
+    uint32_t nl_mode;      // this launch: kNlOff, kNlBuild (the density pass that records the lists) or kNlUse (VelPos)
+    uint32_t nl_still;     // kNlUse: nothing has moved since the lists were recorded (first sub-step of the frame)
     float *p1x, *p1y, *p1z;  // by slot: position at grid-build time (= the bin the particle sits in for the frame)
     uint32_t *nl_ent;      // [slot / 64][nl_cap][slot % 64]: (stencil cell 0..26) << kNlSlotBits | candidate slot, reference
                            //   order; the lists of 64 consecutive slots interleaved: a wave reads one 256 B row per entry

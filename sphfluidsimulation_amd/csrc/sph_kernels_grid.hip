@@ -56,16 +56,38 @@ __global__ void __launch_bounds__(kBlock) k_download_merge(Dev d, const float *_
 
 // ---- cell key + histogram: Bucket.compute:26-29 ------------------------------------------------
 
+// The particle order is last frame's cell order, and few particles change cell in a frame: neighbouring lanes mostly
+// hold the same key.  A run of equal keys in a wave is served by ONE atomic of its first lane (~3.7x fewer atomics).
+struct KeyRun {
+    int head;        // first lane of this lane's run
+    uint32_t len;    // lanes in the run
+};
+__device__ __forceinline__ KeyRun key_run(uint32_t key)
+{
+    const int lane = threadIdx.x & (kWave - 1);
+    const uint32_t prev = __shfl_up(key, 1, kWave);
+    const unsigned long long heads = __ballot(lane == 0 || key != prev);
+    const unsigned long long upto = heads & (lane == kWave - 1 ? ~0ull : ((2ull << lane) - 1ull));
+    const int head = 63 - __clzll((long long)upto);
+    const unsigned long long above = head == kWave - 1 ? 0ull : heads & ~((2ull << head) - 1ull);
+    const int next = above ? __ffsll((long long)above) - 1 : kWave;
+    return KeyRun{head, (uint32_t)(next - head)};
+}
+
 __global__ void __launch_bounds__(kBlock) k_cell_key_hist(Dev d)
 {
     const uint32_t p = blockIdx.x * kBlock + threadIdx.x;
-    if (p >= d.count) return;
-    const float x = d.cur.x[p], y = d.cur.y[p], z = d.cur.z[p];
-    const uint32_t key = bucket_key(d, x, y, z);                               // :26-29
-    d.key[p] = key;
-    atomicAdd(&d.cell_count[key], 1u);
-    if (!(x >= 0.0f && x <= 1.0f && y >= 0.0f && y <= 1.0f && z >= 0.0f && z <= 1.0f))
-        d.counters[kCntIrregular] = 1ull;                                      // only straight from an upload: VelPos clamps
+    const bool valid = p < d.count;
+    uint32_t key = 0xFFFFFFFFu;                                                // no cell: lanes past the end
+    if (valid) {
+        const float x = d.cur.x[p], y = d.cur.y[p], z = d.cur.z[p];
+        key = bucket_key(d, x, y, z);                                          // :26-29
+        d.key[p] = key;
+        if (!(x >= 0.0f && x <= 1.0f && y >= 0.0f && y <= 1.0f && z >= 0.0f && z <= 1.0f))
+            d.counters[kCntIrregular] = 1ull;                                  // only straight from an upload: VelPos clamps
+    }
+    const KeyRun r = key_run(key);
+    if (valid && (int)(threadIdx.x & (kWave - 1)) == r.head) atomicAdd(&d.cell_count[key], r.len);
 }
 
 // ---- exclusive scan of cell_count[0 .. n) -> cell_start[0 .. n], n = num_cells + 1 ------------
@@ -189,10 +211,14 @@ __global__ void __launch_bounds__(kScanThreads) k_scan_final(Dev d, uint32_t n)
 __global__ void __launch_bounds__(kBlock) k_scatter(Dev d, uint2 *__restrict__ order_tmp)
 {
     const uint32_t p = blockIdx.x * kBlock + threadIdx.x;
-    if (p >= d.count) return;
-    const uint32_t key = d.key[p];
-    const uint32_t off = atomicSub(&d.cell_count[key], 1u) - 1u;
-    order_tmp[d.cell_start[key] + off] = make_uint2(d.id[p], p);
+    const bool valid = p < d.count;
+    const uint32_t key = valid ? d.key[p] : 0xFFFFFFFFu;
+    const KeyRun r = key_run(key);                                             // one atomic per run of equal keys
+    const int lane = threadIdx.x & (kWave - 1);
+    uint32_t top = 0;
+    if (valid && lane == r.head) top = atomicSub(&d.cell_count[key], r.len);   // the run takes [top - len, top)
+    top = __shfl(top, r.head, kWave);
+    if (valid) order_tmp[d.cell_start[key] + top - 1u - (uint32_t)(lane - r.head)] = make_uint2(d.id[p], p);
 }
 
 // ---- ascending-id order inside each cell (the CAS race made deterministic) ---------------------

@@ -82,7 +82,10 @@ __global__ void __launch_bounds__(kBlock) k_brick_activity(Dev d, int nbx, int n
     static_assert(kRY * kRZ <= kWave, "one lane per row");
     float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
     bool own_nonempty = false;
-    if (lane < kRY * kRZ) {
+    if (d.nl_still) {                              // first sub-step: every displacement is zero, no chunk boxes yet
+        lo[0] = lo[1] = lo[2] = hi[0] = hi[1] = hi[2] = 0.0f;
+        own_nonempty = true;
+    } else if (lane < kRY * kRZ) {
         const int cy = y0 - 2 + lane % kRY, cz = z0 - 2 + lane / kRY;
         if (cy >= 0 && cz >= 0 && cy < R && cz < R) {
             const int xa = x0 - 2 > 0 ? x0 - 2 : 0, xb = x0 + kNlBX + 1 < R - 1 ? x0 + kNlBX + 1 : R - 1;   // bins xa..xb
@@ -253,7 +256,7 @@ void launch_list_prepare(const Dev &d, hipStream_t s)
 {
     const uint32_t nbx = nl_bricks_x(d.R), nby = nl_bricks_y(d.R), nbz = nl_bricks_z(d.R);
     (void)hipMemsetAsync(d.counters + kCntActiveCount, 0, sizeof(unsigned long long), s);
-    hipLaunchKernelGGL(k_chunk_box, dim3(cdiv(d.count, kBlock)), dim3(kBlock), 0, s, d);
+    if (!d.nl_still) hipLaunchKernelGGL(k_chunk_box, dim3(cdiv(d.count, kBlock)), dim3(kBlock), 0, s, d);
     hipLaunchKernelGGL(k_brick_activity, dim3(cdiv(nbx * nby * nbz, kBlock / kWave)), dim3(kBlock), 0, s, d, (int)nbx,
                        (int)nby, (int)(nbx * nby * nbz));
 }
