@@ -9,10 +9,11 @@ pass + 5 force/integrate sub-steps, on the synthetic dam-break of BASELINE.json
 HBM before the timed region.  Prints ONE JSON line (rank 0).
 
 Extra objects on that line:
-  roofline      dominant kernel (VelPos replacement): algorithmic bytes per launch
+  roofline      dominant kernel (k_velpos_list, the VelPos replacement walking the frame's neighbour
+                lists; k_velpos_brick when lists are off): algorithmic bytes per launch
                 (52 B/particle) / its mean launch duration from HIP events recorded
-                on the engine's stream inside the timed region, against the 8 TB/s HBM peak.
-                The sweeps are FP32-VALU bound, so valu_frac is reported next to it.
+                around that kernel on the engine's stream inside the timed region, against the
+                8 TB/s HBM peak.  The sweeps are FP32-VALU bound: valu_frac is next to it.
   cpu_baseline  oracle/ (CPU restatement of the reference, "port") timed on this host for ONE frame
                 of the same workload, all OpenMP threads; also used to check the GPU result.
 """
@@ -149,10 +150,13 @@ def main():
     ms_per_step = elapsed * 1e3 / a.steps
     value = n * a.steps / elapsed
     pbar = st["candidates_density"] / n
-    vel_ms = st["ms_velpos"] / max(st["launches_velpos"], 1)
-    achieved = BYTES_PER_SUBSTEP * n / (vel_ms * 1e-3) / 1e9 if vel_ms > 0 else 0.0
+    vel_ms = st["ms_velpos"] / max(st["launches_velpos"], 1)           # whole sub-step (all its kernels)
+    listed = st["launches_velpos_list"] > 0
+    kernel = "k_velpos_list" if listed else "k_velpos_brick"
+    kernel_ms = st["ms_velpos_list"] / st["launches_velpos_list"] if listed else vel_ms
+    achieved = BYTES_PER_SUBSTEP * n / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
     valu_tflops = value * pbar * (FLOPS_DENSITY + FLOPS_FORCE * 5) / 1e12
-    traffic, traffic_src = pmc_traffic("k_velpos_brick") if n == 16777216 else (None, None)
+    traffic, traffic_src = pmc_traffic(kernel) if n == 16777216 else (None, None)
     out = {
         "metric": "particle-steps/s", "value": value, "unit": "particle-steps/s", "n_gpus": 1,
         "steps": a.steps, "warmup": warm, "ms_per_step": ms_per_step, "higher_is_better": True,
@@ -160,10 +164,10 @@ def main():
         "config": {"workload": workload, "particles": n, "bucket_resolution": R, "substeps": 5,
                    "mode": "exact_order"},
         "roofline": {
-            "bound": "hbm", "kernel": "k_velpos_brick", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
             "algorithmic_bytes_per_launch": BYTES_PER_SUBSTEP * n,
-            "kernel_ms": vel_ms, "launches": st["launches_velpos"],
+            "kernel_ms": kernel_ms, "launches": st["launches_velpos_list"] if listed else st["launches_velpos"],
             "step_hbm_frac": value * BYTES_PER_STEP / (HBM_PEAK_GBS * 1e9),
             "valu_frac": valu_tflops / VALU_PEAK_TFLOPS,
             "candidates_per_particle": pbar,

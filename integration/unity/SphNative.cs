@@ -51,6 +51,8 @@ public static class SphNative
         public uint max_cell_occupancy, overflowed_cells, dropped_particles, queued_targets;
         public ulong nan_resets, candidates_density, halo_violations;
         public ulong listed_target_substeps, scanned_brick_substeps, list_entries;
+        public double ms_velpos_list;
+        public ulong launches_velpos_list;
     }
 
     [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int sph_version();

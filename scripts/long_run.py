@@ -5,14 +5,16 @@ from sphfluidsimulation_amd import presets
 from sphfluidsimulation_amd.simulation import SphFluidSimulation
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 16777216
 frames = int(sys.argv[2]) if len(sys.argv) > 2 else 200
+chunk = int(sys.argv[3]) if len(sys.argv) > 3 else 20
+lists = (sys.argv[4] != "nolists") if len(sys.argv) > 4 else True
 R = presets.scene_bucket_resolution(n)
 pos0, vel0 = presets.dam_break(n, 0.8, 1)
-sim = SphFluidSimulation(particleNumber=n, bucketResolution=R, damFillRate=0.8, profile=True).Start(pos0, vel0)
+sim = SphFluidSimulation(particleNumber=n, bucketResolution=R, damFillRate=0.8, profile=True, lists=lists).Start(pos0, vel0)
 dt = presets.bench_dt_frame(R)
-for f0 in range(0, frames, 20):
+for f0 in range(0, frames, chunk):
     sim.reset_stats()
-    t = time.perf_counter(); sim.step_n(dt, 20); sim.synchronize(); el = time.perf_counter() - t
+    t = time.perf_counter(); sim.step_n(dt, chunk); sim.synchronize(); el = time.perf_counter() - t
     st = sim.stats()
-    print(f"frames {f0+1}-{f0+20}: {el/20*1e3:7.2f} ms/frame  grid {st['ms_grid']/20:5.2f} density {st['ms_density']/20:5.2f} "
-          f"velpos {st['ms_velpos']/100:5.2f}  max_occ {st['max_cell_occupancy']} overflow_cells {st['overflowed_cells']} "
+    print(f"frames {f0+1}-{f0+chunk}: {el/chunk*1e3:7.2f} ms/frame  grid {st['ms_grid']/chunk:5.2f} density {st['ms_density']/chunk:5.2f} "
+          f"velpos {st['ms_velpos']/(5*chunk):5.2f} listed {st['listed_target_substeps']/(5.0*chunk*n):5.3f}  max_occ {st['max_cell_occupancy']} overflow_cells {st['overflowed_cells']} "
           f"queued {st['queued_targets']} nan {st['nan_resets']} P-bar {st['candidates_density']/n:6.1f}", flush=True)

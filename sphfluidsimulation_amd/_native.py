@@ -91,6 +91,8 @@ class SphStats(C.Structure):
         ("listed_target_substeps", C.c_uint64),
         ("scanned_brick_substeps", C.c_uint64),
         ("list_entries", C.c_uint64),
+        ("ms_velpos_list", C.c_double),
+        ("launches_velpos_list", C.c_uint64),
     ]
 
     def as_dict(self):

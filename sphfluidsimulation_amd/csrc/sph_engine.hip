@@ -19,7 +19,7 @@ static thread_local std::string g_last_error = "";
 
 struct PassEvents {
     hipEvent_t a, b;
-    int kind;  // 0 grid, 1 density, 2 velpos
+    int kind;  // 0 grid, 1 density, 2 velpos (whole pass), 3 k_velpos_list alone
 };
 
 struct SphContext {
@@ -48,8 +48,8 @@ struct SphContext {
     bool profile = false;
     std::vector<PassEvents> pending;
     std::vector<hipEvent_t> free_events;
-    double ms[3] = {0, 0, 0};
-    uint64_t launches[3] = {0, 0, 0};
+    double ms[4] = {0, 0, 0, 0};
+    uint64_t launches[4] = {0, 0, 0, 0};
     std::string last_error;
     // z-slab (multi-GPU) mode
     bool slab = false;
@@ -329,7 +329,16 @@ static int do_velpos(SphContext *c, float dt)
     c->nl_fresh = false;              // positions move: a later density pass of this frame must not record
     {
         PassTimer t(c, 2);
-        launch_velpos(c->dev, c->stream);
+        if (c->profile && c->dev.nl_mode == kNlUse) {   // the dominant kernel on its own, for the roofline figure
+            PassEvents pe{};
+            pe.kind = 3;
+            pe.a = get_event(c);
+            pe.b = get_event(c);
+            launch_velpos(c->dev, c->stream, pe.a, pe.b);
+            c->pending.push_back(pe);
+        } else {
+            launch_velpos(c->dev, c->stream);
+        }
     }
     HIP_TRY(c, hipGetLastError());
     std::swap(c->dev.cur, c->dev.nxt);  // Swap(), SphFluidSimulation.cs:267-268
@@ -684,6 +693,8 @@ int sph_get_stats(SphContext *c, SphStats *out)
     out->launches_grid = c->launches[0];
     out->launches_density = c->launches[1];
     out->launches_velpos = c->launches[2];
+    out->ms_velpos_list = c->ms[3];
+    out->launches_velpos_list = c->launches[3];
     out->max_cell_occupancy = (uint32_t)cnt[kCntMaxOcc];
     out->overflowed_cells = (uint32_t)cnt[kCntOverflowCells];
     out->dropped_particles = (uint32_t)cnt[kCntDropped];
@@ -703,7 +714,7 @@ int sph_reset_stats(SphContext *c)
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     fold_events(c);
-    for (int i = 0; i < 3; i++) {
+    for (int i = 0; i < 4; i++) {
         c->ms[i] = 0;
         c->launches[i] = 0;
     }

@@ -155,7 +155,8 @@ void launch_download_merge(const Dev &d, const float *pw0, int substeps_done, fl
                            float4 *pos4, float4 *vel4, float *rho_by_id, hipStream_t s);
 void launch_grid_build(const Dev &d, hipStream_t s);  // keys, histogram, scan, scatter, id-sort, reorder: cur -> nxt
 void launch_density(const Dev &d, hipStream_t s);     // sph_kernels_brick.hip (tiled) + queue
-void launch_velpos(const Dev &d, hipStream_t s);      // cur -> nxt
+// cur -> nxt; the optional events bracket k_velpos_list (recorded only in a sub-step that uses neighbour lists)
+void launch_velpos(const Dev &d, hipStream_t s, hipEvent_t list_begin = nullptr, hipEvent_t list_end = nullptr);
 void launch_list_prepare(const Dev &d, hipStream_t s);  // sph_kernels_list.hip: which bricks may use their lists
 void launch_velpos_lists(const Dev &d, hipStream_t s);  // sph_kernels_list.hip: the targets of those bricks, cur -> nxt
 

@@ -28,7 +28,7 @@ class SphFluidSimulation:
                  damFillRate: float = 0.5, viscosity: float = 0.01, restDensity: float = 1.5,
                  gasConstant: float = 150.0, stiffnessCoefficient: float = 5000.0,
                  dampingCoefficient: float = 10.0, device_id: int = 0, profile: bool = False,
-                 tiling: bool = True, particleRadius: float = 0.01, lowSpeed: float = 0.0,
+                 tiling: bool = True, lists: bool = True, particleRadius: float = 0.01, lowSpeed: float = 0.0,
                  highSpeed: float = 0.5):
         # inspector fields and defaults, SphFluidSimulation.cs:35-45
         self.preset = preset
@@ -47,6 +47,7 @@ class SphFluidSimulation:
         self.device_id = device_id
         self.profile = profile
         self.tiling = tiling            # False: diagnostic per-target kernels (SPH_FLAG_NO_TILING)
+        self.lists = lists              # False: every sub-step re-scans its 27 bins (SPH_FLAG_NO_LISTS)
         self._ctx = C.c_void_p()
         self._derived = None
 
@@ -62,7 +63,8 @@ class SphFluidSimulation:
         p.stiffness_coeff = self.stiffnessCoefficient
         p.damping_coeff = self.dampingCoefficient
         p.device_id = self.device_id
-        p.flags = (N.SPH_FLAG_PROFILE if self.profile else 0) | (0 if self.tiling else N.SPH_FLAG_NO_TILING)
+        p.flags = ((N.SPH_FLAG_PROFILE if self.profile else 0) | (0 if self.tiling else N.SPH_FLAG_NO_TILING) |
+                   (0 if self.lists else N.SPH_FLAG_NO_LISTS))
         return p
 
     def _check(self, rc):
