@@ -3,7 +3,7 @@ TAG=${1:-r01}
 mkdir -p gpurun_out
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 for C in FETCH_SIZE WRITE_SIZE; do
-  timeout -k 10 600 rocprofv3 --pmc $C --kernel-trace --output-format csv -d gpurun_out/pmc_${TAG}_$C -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/pmc_${TAG}_$C.log 2>&1 || exit 1
+  timeout -k 10 600 rocprofv3 --pmc $C --kernel-trace --output-format csv -d gpurun_out/pmc_${TAG}_$C -- python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline > gpurun_out/pmc_${TAG}_$C.log 2>&1 || exit 1
 done
 timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${TAG} -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/prof_${TAG}.log 2>&1 || exit 1
 python3 - <<PY
@@ -16,9 +16,10 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
             if r["Counter_Name"] == c:
                 agg[r["Kernel_Name"]].append(float(r["Counter_Value"]))
         for k, v in agg.items():
-            out[k][c] = sum(v) / len(v); out[k]["calls_" + c] = len(v)
+            v.sort()
+            out[k][c] = v[len(v) // 2]; out[k]["calls_" + c] = len(v)   # median: the first frame's launches differ (lists blocked)
 with open("gpurun_out/traffic_${TAG}.csv", "w") as fo:
-    fo.write("kernel,avg_FETCH_SIZE_raw,avg_WRITE_SIZE_raw,calls\n")
+    fo.write("kernel,avg_FETCH_SIZE_raw,avg_WRITE_SIZE_raw,calls\n")   # (columns keep their names; values are per-launch medians)
     for k, v in sorted(out.items()):
         fo.write('"%s",%.1f,%.1f,%d\n' % (k, v.get("FETCH_SIZE", 0), v.get("WRITE_SIZE", 0), v.get("calls_FETCH_SIZE", 0)))
 print(open("gpurun_out/traffic_${TAG}.csv").read())

@@ -136,7 +136,7 @@ static void refresh_scalars(SphContext *c)
     d.use_bricks = (p.flags & SPH_FLAG_NO_TILING) ? 0u : 1u;
     // neighbour lists: skin = nl_skin_frac * h; pre-filter radius (h + skin)^2 rounded up like h2_up; a brick is calm
     // while its relative-displacement bound stays below 90 % of the skin (the rest absorbs fp32 rounding of the bound)
-    c->nl_enabled = d.use_bricks && !c->slab && !(p.flags & SPH_FLAG_NO_LISTS) && d.R <= 256u;
+    c->nl_enabled = d.use_bricks && !(p.flags & SPH_FLAG_NO_LISTS) && d.R <= 256u;
     if (const char *e = getenv("SPH_NL_SKIN")) {   // tuning aid: skin / h
         const float v = (float)atof(e);
         if (v > 0.0f && v <= 1.0f) c->nl_skin_frac = v;

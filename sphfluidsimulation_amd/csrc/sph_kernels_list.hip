@@ -168,6 +168,7 @@ __global__ void __launch_bounds__(kBlock, SPH_LIST_MINWAVES) k_velpos_list(Dev d
     uint32_t n = d.nl_cnt[s];
     const uint32_t key = bucket_key(d, qx, qy, qz);                              // the bin, Bucket.compute:26-29
     live = live && key < d.num_cells;                                            // limbo: queued by the brick kernel
+    if (d.ghost && d.ghost[s]) live = false;       // z-slab mode: ghosts are candidates only, their owner integrates them
     const uint32_t brick = live ? nl_brick_of_key(d, key) : 0u;
     live = live && !(d.brick_state[brick] & kBrickActive);                       // else the scanning kernel takes it
     // the stencil now (:58) against the stencil the list was recorded for
@@ -204,6 +205,7 @@ __global__ void __launch_bounds__(kBlock, SPH_LIST_MINWAVES) k_velpos_list(Dev d
                 if (((ax >> (code / 9)) & (ay >> ((code / 3) % 3)) & (az >> (code % 3))) & 1u) mask |= 1u << code;
         }
     }
+    if (live && (c0z + shz < d.zt_lo || c0z + shz > d.zt_hi)) atomicAdd(&d.counters[kCntHaloViolation], 1ull);
     enqueue_block(d, hand_over, s, s_queue);
     const float rho_i = rvi.x;                                                   // :60
     const float p_i = d.gas_const * (rho_i - d.rest_density);                    // :61

@@ -131,6 +131,7 @@ __global__ void __launch_bounds__(kBlock) k_slab_unpack_update(Dev d, uint32_t s
     } else {
         const float *r = in + 7ull * k;
         d.cur.x[s] = r[0]; d.cur.y[s] = r[1]; d.cur.z[s] = r[2];
+        if (d.cur.p4) d.cur.p4[s] = make_float4(r[0], r[1], r[2], 0.0f);   // the packed copy the list kernel gathers
         d.cur.rv[s] = make_float4(r[3], r[4], r[5], r[6]);
     }
 }
