@@ -37,7 +37,7 @@ struct SphContext {
     bool nl_enabled = false, nl_allocated = false;
     bool nl_fresh = false;            // the grid was just built: the next density pass runs on the binned positions
     bool nl_recorded = false;         // ... and recorded the lists the VelPos sub-steps of this frame may use
-    float nl_skin_frac = 0.05f;       // skin / h (profiles/: 0.04-0.06 is the optimum of the 16.7 M dam break)
+    float nl_skin_frac = 0.04f;       // skin / h (profiles/: 0.04-0.06 is the optimum of the 16.7 M dam break)
     float4 *mesh_props = nullptr;     // _particleMeshPropertiesBuffer (:174), allocated on first use
     bool mesh_valid = false;
     bool uploaded = false, grid_valid = false;
@@ -263,7 +263,7 @@ static void ensure_lists(SphContext *c)
     const bool ok = dalloc(c, &d.p1x, n) == SPH_OK && dalloc(c, &d.p1y, n) == SPH_OK && dalloc(c, &d.p1z, n) == SPH_OK &&
                     dalloc(c, &d.nl_ent, (size_t)d.nl_cap * ((n + 63) & ~(size_t)63)) == SPH_OK && dalloc(c, &d.nl_cnt, n) == SPH_OK &&
                     dalloc(c, &d.chunk_box, 6 * ((n + 63) / 64)) == SPH_OK &&
-                    dalloc(c, &d.brick_rho, 3 * bricks) == SPH_OK && dalloc(c, &d.active_list, bricks) == SPH_OK && dalloc(c, &d.brick_state, bricks) == SPH_OK &&
+                    dalloc(c, &d.brick_rho, 3 * bricks) == SPH_OK && dalloc(c, &d.active_list, bricks) == SPH_OK && dalloc(c, &d.queue2, n) == SPH_OK && dalloc(c, &d.brick_state, bricks) == SPH_OK &&
                     dalloc(c, &d.cur.p4, n) == SPH_OK && dalloc(c, &d.nxt.p4, n) == SPH_OK;
     if (!ok) {
         while (c->allocs.size() > before) {
@@ -276,6 +276,7 @@ static void ensure_lists(SphContext *c)
         d.nl_cnt = nullptr;
         d.chunk_box = d.brick_rho = nullptr;
         d.active_list = nullptr;
+        d.queue2 = nullptr;
         d.brick_state = nullptr;
         d.cur.p4 = d.nxt.p4 = nullptr;
         c->nl_enabled = false;

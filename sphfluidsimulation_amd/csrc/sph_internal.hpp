@@ -66,6 +66,7 @@ struct Dev {
     uint32_t nl_cap;
     float *chunk_box;      // [6][chunks]: min x,y,z / max x,y,z of the displacement (cur - p1) over each 64 consecutive slots
     uint32_t n_chunks, n_bricks;
+    uint32_t *queue2;      // [count]: targets that changed cell and may see a bin that entered their stencil
     uint32_t *active_list; // [bricks]: the bricks the scanning kernel must take this sub-step (kNlUse)
     uint8_t *brick_state;  // [bricks]: kBrickUnlisted (set while building), kBrickActive (set per sub-step)
     float *brick_rho;      // [3][bricks]: per-axis bound on |delta_i - delta_j| around the brick, this sub-step
@@ -107,6 +108,7 @@ enum Counter : int {
     kCntActiveBricks,   // non-empty bricks that took the scanning kernel in a list-mode sub-step (since sph_reset_stats)
     kCntListEntries,    // (unused, see kStatListEntries)
     kCntActiveCount,    // length of active_list for the sub-step in flight
+    kCntQueue2,         // length of queue2 (targets k_velpos_list hands to k_velpos_list_changers) for the sub-step in flight
     kCntIrregular,      // last grid build saw a position outside [0,1] (or NaN): bins say nothing about positions
     kCntCount
 };

@@ -136,83 +136,69 @@ __global__ void __launch_bounds__(kBlock) k_brick_activity(Dev d, int nbx, int n
 // Hands the flagged targets of a block to the generic queue with ONE atomic on the queue counter (every thread of the
 // block must call it).  ~1 % of the targets fail condition (2) in a sub-step, i.e. nearly every wave holds one: an
 // atomic per lane, or even per wave, on that single address would serialise the launch (~3 ns each).
-__device__ __forceinline__ void enqueue_block(const Dev &d, bool pred, uint32_t slot, uint32_t *s_cnt)
+__device__ __forceinline__ void enqueue_block(const Dev &d, bool pred, uint32_t slot, uint32_t *s_cnt, uint32_t *queue,
+                                              int counter)
 {
     if (threadIdx.x == 0) s_cnt[0] = 0;
     __syncthreads();
     uint32_t k = 0;
     if (pred) k = atomicAdd(&s_cnt[0], 1u);
     __syncthreads();
-    if (threadIdx.x == 0 && s_cnt[0]) s_cnt[1] = (uint32_t)atomicAdd(&d.counters[kCntQueue], (unsigned long long)s_cnt[0]);
+    if (threadIdx.x == 0 && s_cnt[0]) s_cnt[1] = (uint32_t)atomicAdd(&d.counters[counter], (unsigned long long)s_cnt[0]);
     __syncthreads();
-    if (pred) d.queue[s_cnt[1] + k] = slot;
+    if (pred) queue[s_cnt[1] + k] = slot;
 }
 
-// VelPos.compute:46-158 for the targets of CALM bricks, one lane per slot: pair sums from the list recorded by the
-// frame's first sub-step.  Slot order keeps every per-target stream (9 loads, 6 stores, the 256 B entry rows) fully
-// coalesced; the candidates of 64 consecutive slots (~17 bins of one row and their neighbours, ~20 KB of
-// (x,y,z,-) + (rho,vx,vy,vz)) are gathered through L1/L2 -- there is no tile to stage.  The pair arithmetic
-// (~160 VALU instructions per entry, 14 IEEE divisions per two entries) is what bounds the kernel.
-__global__ void __launch_bounds__(kBlock, SPH_LIST_MINWAVES) k_velpos_list(Dev d)
+// Where a target stands against the stencil its list was recorded for.
+struct ListTarget {
+    float qx, qy, qz;      // where it was binned
+    float px, py, pz;      // where it is now, VelPos.compute:57
+    int c0x, c0y, c0z;     // recorded stencil centre (its bin)
+    int shx, shy, shz;     // current cell - c0
+    uint32_t mask;         // recorded stencil cells (0..26) that are still in the stencil
+};
+
+__device__ __forceinline__ ListTarget list_target(const Dev &d, uint32_t s)
 {
-    __shared__ uint32_t s_queue[2];
-    if (nl_blocked(d)) return;                     // the scanning kernels take everything
-    const uint32_t s_raw = xcd_contiguous_block() * kBlock + threadIdx.x;
-    bool live = s_raw < d.count;
-    const uint32_t s = live ? s_raw : 0u;
+    ListTarget t;
     const int R = (int)d.R;
-    const float qx = d.p1x[s], qy = d.p1y[s], qz = d.p1z[s];                     // where it was binned
-    const float pix = d.cur.x[s], piy = d.cur.y[s], piz = d.cur.z[s];            // :57
+    t.qx = d.p1x[s]; t.qy = d.p1y[s]; t.qz = d.p1z[s];
+    t.px = d.cur.x[s]; t.py = d.cur.y[s]; t.pz = d.cur.z[s];
+    t.c0x = cell_coord(t.qx, d.Rm1, R); t.c0y = cell_coord(t.qy, d.Rm1, R); t.c0z = cell_coord(t.qz, d.Rm1, R);
+    t.shx = cell_coord(t.px, d.Rm1, R) - t.c0x;                                  // :58
+    t.shy = cell_coord(t.py, d.Rm1, R) - t.c0y;
+    t.shz = cell_coord(t.pz, d.Rm1, R) - t.c0z;
+    t.mask = 0x7FFFFFFu;
+    return t;
+}
+
+__device__ __forceinline__ bool one_cell_away(const ListTarget &t)
+{
+    return t.shx >= -1 && t.shx <= 1 && t.shy >= -1 && t.shy <= 1 && t.shz >= -1 && t.shz <= 1;
+}
+
+// offsets {-1,0,1} of the recorded stencil that lie within one cell of the shifted centre, per axis -> cell mask
+__device__ __forceinline__ uint32_t shifted_mask(const ListTarget &t)
+{
+    const uint32_t ax = t.shx > 0 ? 6u : (t.shx < 0 ? 3u : 7u), ay = t.shy > 0 ? 6u : (t.shy < 0 ? 3u : 7u),
+                   az = t.shz > 0 ? 6u : (t.shz < 0 ? 3u : 7u);
+    uint32_t mask = 0;
+#pragma unroll
+    for (int code = 0; code < 27; code++)
+        if (((ax >> (code / 9)) & (ay >> ((code / 3) % 3)) & (az >> (code % 3))) & 1u) mask |= 1u << code;
+    return mask;
+}
+
+// The pair sums of VelPos.compute:67-98 from the recorded list of slot s (n entries), then :100-157.
+__device__ __forceinline__ void walk_list_and_integrate(const Dev &d, uint32_t s, uint32_t n, uint32_t mask, bool live,
+                                                        float pix, float piy, float piz)
+{
     const float4 rvi = d.cur.rv[s];
     const float viw = d.cur.vw[s];
-    uint32_t n = d.nl_cnt[s];
-    const uint32_t key = bucket_key(d, qx, qy, qz);                              // the bin, Bucket.compute:26-29
-    live = live && key < d.num_cells;                                            // limbo: queued by the brick kernel
-    if (d.ghost && d.ghost[s]) live = false;       // z-slab mode: ghosts are candidates only, their owner integrates them
-    const uint32_t brick = live ? nl_brick_of_key(d, key) : 0u;
-    live = live && !(d.brick_state[brick] & kBrickActive);                       // else the scanning kernel takes it
-    // the stencil now (:58) against the stencil the list was recorded for
-    const int c0x = cell_coord(qx, d.Rm1, R), c0y = cell_coord(qy, d.Rm1, R), c0z = cell_coord(qz, d.Rm1, R);
-    const int shx = cell_coord(pix, d.Rm1, R) - c0x, shy = cell_coord(piy, d.Rm1, R) - c0y,
-              shz = cell_coord(piz, d.Rm1, R) - c0z;
-    uint32_t mask = 0x7FFFFFFu;                    // recorded stencil cells that are still in the stencil
-    bool hand_over = false;
-    if (live && (shx | shy | shz) != 0) {
-        // condition (2): at most one cell away, and -- along every axis it crossed a face of -- deeper behind that face
-        // when the lists were built than any two particles around the brick have moved apart along that axis since
-        // (cell units; the constants absorb the fp32 rounding of u and of the ranges)
-        const float nx = d.brick_rho[brick] * d.Rm1 * 1.0001f + 1e-4f,
-                    ny = d.brick_rho[(size_t)d.n_bricks + brick] * d.Rm1 * 1.0001f + 1e-4f,
-                    nz = d.brick_rho[2 * (size_t)d.n_bricks + brick] * d.Rm1 * 1.0001f + 1e-4f;
-        const float ux = qx * d.Rm1, uy = qy * d.Rm1, uz = qz * d.Rm1;
-        bool ok = shx >= -1 && shx <= 1 && shy >= -1 && shy <= 1 && shz >= -1 && shz <= 1;
-        if (shx > 0) ok = ok && ((float)(c0x + 1) - ux >= nx);
-        if (shx < 0) ok = ok && (ux - (float)c0x >= nx);
-        if (shy > 0) ok = ok && ((float)(c0y + 1) - uy >= ny);
-        if (shy < 0) ok = ok && (uy - (float)c0y >= ny);
-        if (shz > 0) ok = ok && ((float)(c0z + 1) - uz >= nz);
-        if (shz < 0) ok = ok && (uz - (float)c0z >= nz);
-        if (!ok) {
-            hand_over = true;                      // the generic per-target kernel scans for this one
-            live = false;
-        } else {
-            // offsets {-1,0,1} of the recorded stencil within one cell of the shifted centre, per axis
-            const uint32_t ax = shx > 0 ? 6u : (shx < 0 ? 3u : 7u), ay = shy > 0 ? 6u : (shy < 0 ? 3u : 7u),
-                           az = shz > 0 ? 6u : (shz < 0 ? 3u : 7u);
-            mask = 0;
-#pragma unroll
-            for (int code = 0; code < 27; code++)
-                if (((ax >> (code / 9)) & (ay >> ((code / 3) % 3)) & (az >> (code % 3))) & 1u) mask |= 1u << code;
-        }
-    }
-    if (live && (c0z + shz < d.zt_lo || c0z + shz > d.zt_hi)) atomicAdd(&d.counters[kCntHaloViolation], 1ull);
-    enqueue_block(d, hand_over, s, s_queue);
     const float rho_i = rvi.x;                                                   // :60
     const float p_i = d.gas_const * (rho_i - d.rest_density);                    // :61
     const float vix = rvi.y, viy = rvi.z, viz = rvi.w;                           // :62
     Force f{0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};                                 // :64-65
-    if (!live) n = 0;
-
     struct Cand {
         float x, y, z, rho, vx, vy, vz;
         bool take;
@@ -248,8 +234,111 @@ __global__ void __launch_bounds__(kBlock, SPH_LIST_MINWAVES) k_velpos_list(Dev d
         }
     }
     if (live) integrate_store(d, s, pix, piy, piz, vix, viy, viz, viw, rho_i, f);  // :100-157
+}
+
+// VelPos.compute:46-158 for the targets of CALM bricks, one lane per slot: pair sums from the list recorded by the
+// frame's first sub-step.  Slot order keeps every per-target stream (9 loads, 6 stores, the 256 B entry rows) fully
+// coalesced; the candidates of 64 consecutive slots (~17 bins of one row and their neighbours, ~20 KB of
+// (x,y,z,-) + (rho,vx,vy,vz)) are gathered through L1/L2 -- there is no tile to stage.  The pair arithmetic
+// (~160 VALU instructions per entry, 14 IEEE divisions per two entries) is what bounds the kernel.
+__global__ void __launch_bounds__(kBlock, SPH_LIST_MINWAVES) k_velpos_list(Dev d)
+{
+    __shared__ uint32_t s_queue[2];
+    if (nl_blocked(d)) return;                     // the scanning kernels take everything
+    const uint32_t s_raw = xcd_contiguous_block() * kBlock + threadIdx.x;
+    bool live = s_raw < d.count;
+    const uint32_t s = live ? s_raw : 0u;
+    ListTarget t = list_target(d, s);
+    uint32_t n = d.nl_cnt[s];
+    const uint32_t key = bucket_key(d, t.qx, t.qy, t.qz);                        // the bin, Bucket.compute:26-29
+    live = live && key < d.num_cells;                                            // limbo: queued by the brick kernel
+    if (d.ghost && d.ghost[s]) live = false;       // z-slab mode: ghosts are candidates only, their owner integrates them
+    const uint32_t brick = live ? nl_brick_of_key(d, key) : 0u;
+    live = live && !(d.brick_state[brick] & kBrickActive);                       // else the scanning kernel takes it
+    bool hand_over = false;
+    if (live && (t.shx | t.shy | t.shz) != 0) {
+        // condition (2): at most one cell away, and -- along every axis it crossed a face of -- deeper behind that face
+        // when the lists were built than any two particles around the brick have moved apart along that axis since
+        // (cell units; the constants absorb the fp32 rounding of u and of the ranges)
+        const float nx = d.brick_rho[brick] * d.Rm1 * 1.0001f + 1e-4f,
+                    ny = d.brick_rho[(size_t)d.n_bricks + brick] * d.Rm1 * 1.0001f + 1e-4f,
+                    nz = d.brick_rho[2 * (size_t)d.n_bricks + brick] * d.Rm1 * 1.0001f + 1e-4f;
+        const float ux = t.qx * d.Rm1, uy = t.qy * d.Rm1, uz = t.qz * d.Rm1;
+        bool ok = one_cell_away(t);
+        if (t.shx > 0) ok = ok && ((float)(t.c0x + 1) - ux >= nx);
+        if (t.shx < 0) ok = ok && (ux - (float)t.c0x >= nx);
+        if (t.shy > 0) ok = ok && ((float)(t.c0y + 1) - uy >= ny);
+        if (t.shy < 0) ok = ok && (uy - (float)t.c0y >= ny);
+        if (t.shz > 0) ok = ok && ((float)(t.c0z + 1) - uz >= nz);
+        if (t.shz < 0) ok = ok && (uz - (float)t.c0z >= nz);
+        if (!ok) {
+            hand_over = true;                      // k_velpos_list_changers looks into the bins that entered the stencil
+            live = false;
+        } else {
+            t.mask = shifted_mask(t);
+        }
+    }
+    if (live && (t.c0z + t.shz < d.zt_lo || t.c0z + t.shz > d.zt_hi)) atomicAdd(&d.counters[kCntHaloViolation], 1ull);
+    enqueue_block(d, hand_over, s, s_queue, d.queue2, kCntQueue2);
+    if (!live) n = 0;
+    walk_list_and_integrate(d, s, n, t.mask, live, t.px, t.py, t.pz);
     stat_add(d, kStatListed, live ? 1ull : 0ull);
     stat_add(d, kStatListEntries, (unsigned long long)n);
+}
+
+// The targets k_velpos_list handed over: they sit in a cell next to their bin and close behind the face they crossed,
+// so a bin that ENTERED their stencil might hold a candidate within h.  One lane per such target looks (distance
+// pre-test on the listed particles of those <= 19 bins): almost never -- then the recorded list, minus the bins that
+// left the stencil, is complete and the target is integrated here; otherwise, and when it is more than one cell away,
+// the generic scanning kernel takes it.
+__global__ void __launch_bounds__(kBlock, SPH_LIST_MINWAVES) k_velpos_list_changers(Dev d)
+{
+    const uint32_t qlen = (uint32_t)d.counters[kCntQueue2];
+    unsigned long long served = 0, entries = 0;
+    for (uint32_t q0 = blockIdx.x * kBlock; q0 < qlen; q0 += gridDim.x * kBlock) {   // block-uniform
+        const uint32_t q = q0 + threadIdx.x;
+        bool live = q < qlen;
+        const uint32_t s = d.queue2[live ? q : qlen - 1];
+        ListTarget t = list_target(d, s);
+        const int R = (int)d.R;
+        bool generic = live && !one_cell_away(t);
+        if (live && !generic) {
+            // bins of the current stencil that are not in the recorded one: beyond c0 +- 1 on an axis that moved
+            const int cx = t.c0x + t.shx, cy = t.c0y + t.shy, cz = t.c0z + t.shz;
+            for (int code = 0; code < 27 && !generic; code++) {
+                const int bx = cx + code / 9 - 1, by = cy + (code / 3) % 3 - 1, bz = cz + code % 3 - 1;
+                const bool recorded = bx >= t.c0x - 1 && bx <= t.c0x + 1 && by >= t.c0y - 1 && by <= t.c0y + 1 &&
+                                      bz >= t.c0z - 1 && bz <= t.c0z + 1;
+                if (recorded) continue;
+                const CellRange cr = cell_range(d, bx, by, bz);                  // bounds test :73 + the bucket row
+                for (uint32_t k = 0; k < cr.cnt; k++) {
+                    const float4 pj = d.cur.p4[cr.start + k];
+                    const float rx = t.px - pj.x, ry = t.py - pj.y, rz = t.pz - pj.z;
+                    if (__builtin_fmaf(rz, rz, __builtin_fmaf(ry, ry, rx * rx)) < d.h2_up) generic = true;   // superset of |r| < h
+                }
+            }
+        }
+        // (wave-aggregated: this is rare)
+        {
+            const unsigned long long m = __ballot(generic);
+            if (m) {
+                const int lane = threadIdx.x & (kWave - 1), leader = __ffsll((long long)m) - 1;
+                unsigned long long base = 0;
+                if (lane == leader) base = atomicAdd(&d.counters[kCntQueue], (unsigned long long)__popcll(m));
+                base = __shfl(base, leader, kWave);
+                if (generic) d.queue[base + (unsigned long long)__popcll(m & ((1ull << lane) - 1ull))] = s;
+            }
+        }
+        live = live && !generic;
+        if (live && (t.c0z + t.shz < d.zt_lo || t.c0z + t.shz > d.zt_hi)) atomicAdd(&d.counters[kCntHaloViolation], 1ull);
+        const uint32_t n = live ? d.nl_cnt[s] : 0u;
+        walk_list_and_integrate(d, s, n, shifted_mask(t), live, t.px, t.py, t.pz);
+        served += live ? 1ull : 0ull;
+        entries += n;
+        (void)R;
+    }
+    stat_add(d, kStatListed, served);
+    stat_add(d, kStatListEntries, entries);
 }
 
 static inline uint32_t cdiv(uint32_t a, uint32_t b) { return a ? (a + b - 1) / b : 1u; }
@@ -265,7 +354,10 @@ void launch_list_prepare(const Dev &d, hipStream_t s)
 
 void launch_velpos_lists(const Dev &d, hipStream_t s)
 {
+    (void)hipMemsetAsync(d.counters + kCntQueue2, 0, sizeof(unsigned long long), s);
     hipLaunchKernelGGL(k_velpos_list, dim3(cdiv(d.count, kBlock)), dim3(kBlock), 0, s, d);
+    const uint32_t g = cdiv(d.count, kBlock);
+    hipLaunchKernelGGL(k_velpos_list_changers, dim3(g < 1024u ? g : 1024u), dim3(kBlock), 0, s, d);
 }
 
 }  // namespace sph
