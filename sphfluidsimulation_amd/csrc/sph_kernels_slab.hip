@@ -37,31 +37,54 @@ __device__ __forceinline__ void write_record(float *buf, uint32_t k, const Dev &
     r[8] = __uint_as_float(d.id[p]);
 }
 
+// Stream compaction into up to three output lists at once: every thread of the block calls it with the list it
+// appends to (0..2, or -1 for none) and gets its index in that list.  ONE global atomic per list and block: an atomic
+// per particle on a single counter costs ~3 ns each whatever else the kernel does (3 ms per frame at 16.7 M).
+__device__ __forceinline__ uint32_t block_append3(int which, uint32_t *counters, uint32_t *s_cnt /* [6] */)
+{
+    const int lane = threadIdx.x & (kWave - 1);
+    if (threadIdx.x < 3) s_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    uint32_t in_block = 0;
+#pragma unroll
+    for (int w = 0; w < 3; w++) {
+        const unsigned long long m = __ballot(which == w);
+        if (m == 0ull) continue;                   // wave-uniform
+        uint32_t wave_off = 0;
+        if (lane == __ffsll((long long)m) - 1) wave_off = atomicAdd(&s_cnt[w], (uint32_t)__popcll(m));
+        wave_off = __shfl(wave_off, __ffsll((long long)m) - 1, kWave);
+        if (which == w) in_block = wave_off + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+    }
+    __syncthreads();
+    if (threadIdx.x < 3 && s_cnt[threadIdx.x]) s_cnt[3 + threadIdx.x] = atomicAdd(&counters[threadIdx.x], s_cnt[threadIdx.x]);
+    __syncthreads();
+    return which >= 0 ? s_cnt[3 + which] + in_block : 0u;
+}
+
 // Frame start: drop last frame's ghosts, keep the particles whose bucket row is still in this slab
 // (compacted into nxt), pack the ones that crossed into a neighbour's slab.
 __global__ void __launch_bounds__(kBlock) k_slab_classify(Dev d, SlabArgs a)
 {
+    __shared__ uint32_t s_cnt[6];
     const uint32_t s = blockIdx.x * kBlock + threadIdx.x;
-    if (s >= d.count) return;
-    if (d.ghost[s]) return;
-    const uint32_t key = bucket_key(d, d.cur.x[s], d.cur.y[s], d.cur.z[s]);
-    int dest = 0;
-    if (key < d.num_cells) {
-        const int cz = (int)(key / (d.R * d.R));
-        if (cz < a.z_lo) dest = -1;
-        else if (cz >= a.z_hi) dest = 1;
+    int which = -1;                                // 0 keep, 1 to the left neighbour, 2 to the right one
+    if (s < d.count && !d.ghost[s]) {
+        const uint32_t key = bucket_key(d, d.cur.x[s], d.cur.y[s], d.cur.z[s]);
+        which = 0;
+        if (key < d.num_cells) {
+            const int cz = (int)(key / (d.R * d.R));
+            if (cz < a.z_lo && a.has_left) which = 1;          // (a particle cannot lie beyond a missing neighbour)
+            else if (cz >= a.z_hi && a.has_right) which = 2;
+        }
     }
-    if ((dest < 0 && !a.has_left) || (dest > 0 && !a.has_right)) dest = 0;  // cannot happen with a full cover
-    if (dest == 0) {
-        const uint32_t k = atomicAdd(&a.counters[0], 1u);
+    const uint32_t k = block_append3(which, a.counters, s_cnt);
+    if (which == 0) {
         d.nxt.x[k] = d.cur.x[s]; d.nxt.y[k] = d.cur.y[s]; d.nxt.z[k] = d.cur.z[s];
         d.nxt.rv[k] = d.cur.rv[s];
         d.nxt.vw[k] = d.cur.vw[s];
         d.id_nxt[k] = d.id[s];
-    } else {
-        const int side = dest < 0 ? 0 : 1;
-        const uint32_t k = atomicAdd(&a.counters[1 + side], 1u);
-        if (k < a.cap_records) write_record(a.send[side], k, d, s);
+    } else if (which > 0) {
+        if (k < a.cap_records) write_record(a.send[which - 1], k, d, s);
     }
 }
 
@@ -81,24 +104,27 @@ __global__ void __launch_bounds__(kBlock) k_slab_append(Dev d, const float *__re
 // Owned particles binned into the W boundary planes of either face become the neighbour's ghosts.
 __global__ void __launch_bounds__(kBlock) k_slab_export(Dev d, SlabArgs a)
 {
+    __shared__ uint32_t s_cnt[6];
     const uint32_t p = blockIdx.x * kBlock + threadIdx.x;
-    if (p >= d.n_owned) return;
-    const uint32_t key = bucket_key(d, d.cur.x[p], d.cur.y[p], d.cur.z[p]);
-    if (key >= d.num_cells) return;
-    const int cz = (int)(key / (d.R * d.R));
-    if (a.has_left && cz < a.z_lo + a.halo_w) {
-        const uint32_t k = atomicAdd(&a.counters[1], 1u);
-        if (k < a.cap_records) {
-            write_record(a.send[0], k, d, p);
-            a.send_src[0][k] = p;
+    bool to_left = false, to_right = false;
+    if (p < d.n_owned) {
+        const uint32_t key = bucket_key(d, d.cur.x[p], d.cur.y[p], d.cur.z[p]);
+        if (key < d.num_cells) {
+            const int cz = (int)(key / (d.R * d.R));
+            to_left = a.has_left && cz < a.z_lo + a.halo_w;
+            to_right = a.has_right && cz >= a.z_hi - a.halo_w;
         }
     }
-    if (a.has_right && cz >= a.z_hi - a.halo_w) {
-        const uint32_t k = atomicAdd(&a.counters[2], 1u);
-        if (k < a.cap_records) {
-            write_record(a.send[1], k, d, p);
-            a.send_src[1][k] = p;
-        }
+    // (a slab thinner than 2 * halo_w exports a particle to both sides: two passes)
+    const uint32_t kl = block_append3(to_left ? 1 : -1, a.counters, s_cnt);
+    if (to_left && kl < a.cap_records) {
+        write_record(a.send[0], kl, d, p);
+        a.send_src[0][kl] = p;
+    }
+    const uint32_t kr = block_append3(to_right ? 2 : -1, a.counters, s_cnt);
+    if (to_right && kr < a.cap_records) {
+        write_record(a.send[1], kr, d, p);
+        a.send_src[1][kr] = p;
     }
 }
 
@@ -140,10 +166,11 @@ __global__ void __launch_bounds__(kBlock) k_slab_unpack_update(Dev d, uint32_t s
 __global__ void __launch_bounds__(kBlock) k_slab_download(Dev d, int substeps_done, float dt_last, uint32_t *counter,
                                                           uint32_t *ids, float4 *pos4, float4 *vel4, float *rho)
 {
+    __shared__ uint32_t s_cnt[6];
     const uint32_t s = blockIdx.x * kBlock + threadIdx.x;
-    if (s >= d.count) return;
-    if (d.ghost[s]) return;
-    const uint32_t k = atomicAdd(counter, 1u);
+    const bool mine = s < d.count && !d.ghost[s];
+    const uint32_t k = block_append3(mine ? 0 : -1, counter, s_cnt);
+    if (!mine) return;
     const float4 rv = d.cur.rv[s];
     const float vw = d.cur.vw[s];
     const float pw = substeps_done > 0 ? clamp01(1.0f + dt_last * vw) : 1.0f;   // VelPos.compute:153-154
