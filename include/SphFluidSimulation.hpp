@@ -77,6 +77,13 @@ public:
     }
     // 20 floats per particle (MeshProperties, :16-29), record index = texel id
     void DownloadMeshProperties(float *props20) { check(sph_download_mesh_properties(ctx_, props20)); }
+    // row f4: dma-buf fd of that buffer for a renderer on the same GPU (VK_KHR_external_memory_fd); the caller closes it
+    int ExportMeshPropertiesFd(size_t *bytes = nullptr)
+    {
+        int fd = -1;
+        check(sph_export_mesh_properties_fd(ctx_, &fd, bytes));
+        return fd;
+    }
 
     void BucketGeneration() { check(sph_bucket_generation(ctx_)); }                          // :203-221
     void DensityCalculation() { check(sph_density_calculation(ctx_)); }                      // :223-241

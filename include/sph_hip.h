@@ -162,6 +162,13 @@ int sph_update_mesh_properties(SphContext *ctx, const SphMeshParams *mesh);
 int sph_download_mesh_properties(SphContext *ctx, float *props20);
 /* The device buffer itself (valid until sph_destroy), for a renderer that can import device memory (row f4). */
 int sph_mesh_properties_device_ptr(SphContext *ctx, void **device_ptr, size_t *bytes);
+/* Row f4, zero-copy hand-over: moves that buffer (once) into exportable device memory and returns a NEW POSIX file
+ * descriptor for it (dma-buf) that another API on the same GPU can import without a copy -- Vulkan through
+ * VK_KHR_external_memory_fd, which is what Unity's Linux renderer would use for _particleMeshPropertiesBuffer, or
+ * another process through hipMemImportFromShareableHandle.  The caller owns (closes) the fd; the memory lives until
+ * sph_destroy; `bytes` is the size of the allocation (num_particles * 80 rounded up to the device's granularity).
+ * Later sph_update_mesh_properties calls write into the exported memory.  SPH_E_UNSUPPORTED if the driver cannot export. */
+int sph_export_mesh_properties_fd(SphContext *ctx, int *fd, size_t *bytes);
 
 /* One Update() (SphFluidSimulation.cs:96-102) with Time.deltaTime = delta_time:
  * BucketGeneration, DensityCalculation, substeps x UpdateVelocityAndPosition(delta_time/25). */

@@ -74,6 +74,8 @@ public static class SphNative
     [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int sph_update_mesh_properties(IntPtr ctx, ref SphMeshParams mesh);
     [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int sph_download_mesh_properties(IntPtr ctx, [Out] float[] props20);
     [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int sph_mesh_properties_device_ptr(IntPtr ctx, out IntPtr devicePtr, out UIntPtr bytes);
+    // row f4: dma-buf fd of the render-feed buffer for VK_KHR_external_memory_fd (the caller closes the fd)
+    [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int sph_export_mesh_properties_fd(IntPtr ctx, out int fd, out UIntPtr bytes);
     [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int sph_download(IntPtr ctx, float[] pos4, float[] vel4, float[] rho);
     [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int sph_step(IntPtr ctx, float deltaTime);
     [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int sph_step_n(IntPtr ctx, float deltaTime, int frames);

@@ -125,6 +125,7 @@ SYMBOLS = {
     "sph_update_mesh_properties": (C.c_int, [_CTX, C.POINTER(SphMeshParams)]),
     "sph_download_mesh_properties": (C.c_int, [_CTX, _FP]),
     "sph_mesh_properties_device_ptr": (C.c_int, [_CTX, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
+    "sph_export_mesh_properties_fd": (C.c_int, [_CTX, C.POINTER(C.c_int), C.POINTER(C.c_size_t)]),
     "sph_step": (C.c_int, [_CTX, C.c_float]),
     "sph_step_n": (C.c_int, [_CTX, C.c_float, C.c_int]),
     "sph_bucket_generation": (C.c_int, [_CTX]),

@@ -40,6 +40,10 @@ struct SphContext {
     float nl_skin_frac = 0.04f;       // skin / h (profiles/: 0.04-0.06 is the optimum of the 16.7 M dam break)
     float4 *mesh_props = nullptr;     // _particleMeshPropertiesBuffer (:174), allocated on first use
     bool mesh_valid = false;
+    // row f4: the same buffer in exportable device memory (HIP virtual-memory allocation), once a caller asked for its fd
+    hipMemGenericAllocationHandle_t mesh_handle{};
+    void *mesh_va = nullptr;
+    size_t mesh_va_size = 0;
     bool uploaded = false, grid_valid = false;
     int substeps_since_upload = 0;
     float dt_last = 0.0f;
@@ -487,6 +491,11 @@ int sph_destroy(SphContext *c)
     fold_events(c);
     for (hipEvent_t e : c->free_events) (void)hipEventDestroy(e);
     for (void *p : c->allocs) (void)hipFree(p);
+    if (c->mesh_va) {
+        (void)hipMemUnmap(c->mesh_va, c->mesh_va_size);
+        (void)hipMemAddressFree(c->mesh_va, c->mesh_va_size);
+        (void)hipMemRelease(c->mesh_handle);
+    }
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return SPH_OK;
@@ -592,6 +601,61 @@ int sph_mesh_properties_device_ptr(SphContext *c, void **dptr, size_t *bytes)
     if (!c->mesh_valid) return fail(c, SPH_E_BAD_STATE, "no mesh properties yet: call sph_update_mesh_properties first");
     *dptr = c->mesh_props;
     if (bytes) *bytes = (size_t)c->dev.count * 80;
+    return SPH_OK;
+}
+
+int sph_export_mesh_properties_fd(SphContext *c, int *fd, size_t *bytes)
+{
+    if (!c) return fail(nullptr, SPH_E_INVALID_ARG, "ctx is NULL");
+    if (!fd) return fail(c, SPH_E_INVALID_ARG, "fd is NULL");
+    if (c->slab) return fail(c, SPH_E_BAD_STATE, "slab context: no render feed");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t used = (size_t)c->dev.count * 80;
+    if (!c->mesh_va) {
+        // move the render-feed buffer into a shareable physical allocation mapped at a reserved address
+        hipMemAllocationProp prop{};
+        prop.type = hipMemAllocationTypePinned;
+        prop.location.type = hipMemLocationTypeDevice;
+        prop.location.id = c->device;
+        prop.requestedHandleTypes = hipMemHandleTypePosixFileDescriptor;
+        size_t gran = 0;
+        if (hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityMinimum) != hipSuccess || gran == 0) {
+            (void)hipGetLastError();
+            return fail(c, SPH_E_UNSUPPORTED, "this device / driver has no exportable (virtual-memory) allocations");
+        }
+        const size_t size = (used + gran - 1) / gran * gran;
+        hipMemGenericAllocationHandle_t h{};
+        void *va = nullptr;
+        if (hipMemCreate(&h, size, &prop, 0) != hipSuccess) {
+            (void)hipGetLastError();
+            return fail(c, SPH_E_UNSUPPORTED, "hipMemCreate of an exportable allocation failed");
+        }
+        hipMemAccessDesc acc{};
+        acc.location.type = hipMemLocationTypeDevice;
+        acc.location.id = c->device;
+        acc.flags = hipMemAccessFlagsProtReadWrite;
+        if (hipMemAddressReserve(&va, size, 0, nullptr, 0) != hipSuccess || hipMemMap(va, size, 0, h, 0) != hipSuccess ||
+            hipMemSetAccess(va, size, &acc, 1) != hipSuccess) {
+            (void)hipGetLastError();
+            if (va) (void)hipMemAddressFree(va, size);
+            (void)hipMemRelease(h);
+            return fail(c, SPH_E_HIP, "mapping the exportable allocation failed");
+        }
+        if (c->mesh_valid)   // keep what sph_update_mesh_properties already produced
+            HIP_TRY(c, hipMemcpyAsync(va, c->mesh_props, used, hipMemcpyDeviceToDevice, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        c->mesh_handle = h;
+        c->mesh_va = va;
+        c->mesh_va_size = size;
+        c->mesh_props = (float4 *)va;   // (a former hipMalloc'ed buffer stays in c->allocs until sph_destroy)
+    }
+    int out = -1;
+    if (hipMemExportToShareableHandle(&out, c->mesh_handle, hipMemHandleTypePosixFileDescriptor, 0) != hipSuccess || out < 0) {
+        (void)hipGetLastError();
+        return fail(c, SPH_E_UNSUPPORTED, "hipMemExportToShareableHandle failed: no dma-buf export on this system");
+    }
+    *fd = out;
+    if (bytes) *bytes = c->mesh_va_size;
     return SPH_OK;
 }
 

@@ -221,6 +221,9 @@ __device__ __forceinline__ void walk_list_and_integrate(const Dev &d, uint32_t s
         // two entries per trip; the entry words run two trips ahead of the arithmetic, their gathers one trip
         uint32_t w2 = word(2), w3 = word(3);
         Cand a0 = gather(word(0)), a1 = gather(word(1));
+#ifdef SPH_LIST_UNROLL
+#pragma unroll SPH_LIST_UNROLL
+#endif
         for (uint32_t e = 0; e < n; e += 2) {
             const Cand b0 = gather(w2), b1 = gather(w3);
             w2 = word(e + 4);

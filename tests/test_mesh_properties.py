@@ -140,3 +140,60 @@ def test_gpu_mesh_properties_weird_inputs_and_errors():
         assert ptr.value and nbytes.value == n * 80
     finally:
         sim.OnDestroy()
+
+
+@pytest.mark.gpu
+def test_gpu_mesh_properties_zero_copy_export():
+    """Row f4: the render-feed buffer as a dma-buf file descriptor.  Imported again through the HIP runtime itself
+    (hipMemImportFromShareableHandle + a second mapping -- what a Vulkan importer does with VK_KHR_external_memory_fd),
+    the mapping shows the records without any copy by this library, including those of a LATER update."""
+    import ctypes as C
+    import os
+    from sphfluidsimulation_amd.simulation import SphFluidSimulation
+    from sphfluidsimulation_amd import _native as N
+    n = 16384
+    pos0, vel0 = presets.dam_break(n, 0.8, seed=8, jitter=0.3)
+    vel0[:, :3] = np.random.default_rng(2).standard_normal((n, 3)).astype(f32) * f32(0.2)
+    sim = SphFluidSimulation(particleNumber=n, bucketResolution=19, damFillRate=0.8).Start(pos0, vel0)
+    hip = C.CDLL("libamdhip64.so")
+    try:
+        sim.UpdateMeshProperties()
+        before = sim.download_mesh_properties()
+        fd, size = C.c_int(-1), C.c_size_t(0)
+        rc = N.lib().sph_export_mesh_properties_fd(sim._ctx, C.byref(fd), C.byref(size))
+        if rc == N.SPH_E_UNSUPPORTED:
+            pytest.skip("no exportable device memory on this system: " + N.lib().sph_last_error(sim._ctx).decode())
+        assert rc == 0 and fd.value >= 0 and size.value >= n * 80
+        assert np.array_equal(_bits(sim.download_mesh_properties()), _bits(before))      # survived the move
+
+        class Loc(C.Structure):
+            _fields_ = [("type", C.c_int), ("id", C.c_int)]
+
+        class Acc(C.Structure):
+            _fields_ = [("location", Loc), ("flags", C.c_int)]
+
+        handle, va = C.c_void_p(), C.c_void_p()
+        assert hip.hipMemImportFromShareableHandle(C.byref(handle), C.c_void_p(fd.value), 1) == 0     # PosixFileDescriptor
+        assert hip.hipMemAddressReserve(C.byref(va), C.c_size_t(size.value), C.c_size_t(0), None, C.c_ulonglong(0)) == 0
+        assert hip.hipMemMap(va, C.c_size_t(size.value), C.c_size_t(0), handle, C.c_ulonglong(0)) == 0
+        acc = Acc(Loc(1, 0), 3)                                                                          # device 0, read-write
+        assert hip.hipMemSetAccess(va, C.c_size_t(size.value), C.byref(acc), C.c_size_t(1)) == 0
+
+        def read_import():
+            out = np.empty((n, 20), f32)
+            sim.synchronize()
+            assert hip.hipMemcpy(out.ctypes.data_as(C.c_void_p), va, C.c_size_t(n * 80), 2) == 0        # DeviceToHost
+            return out
+
+        assert np.array_equal(_bits(read_import()), _bits(before))
+        sim.Update(1 / 600)
+        sim.UpdateMeshProperties()                   # writes into the exported memory
+        after = sim.download_mesh_properties()
+        assert not np.array_equal(_bits(after), _bits(before))
+        assert np.array_equal(_bits(read_import()), _bits(after))
+        assert hip.hipMemUnmap(va, C.c_size_t(size.value)) == 0
+        hip.hipMemAddressFree(va, C.c_size_t(size.value))
+        hip.hipMemRelease(handle)
+        os.close(fd.value)
+    finally:
+        sim.OnDestroy()
