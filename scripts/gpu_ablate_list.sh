@@ -1,7 +1,8 @@
-# usage: bash scripts/gpu_ablate_list.sh "4 5 0"   (on the GPU box) -> k_velpos_list time per SPH_ABLATE variant
+# usage: bash scripts/gpu_ablate_list.sh "5 0" ["-DSPH_LIST_MINWAVES=5 ..."]  (on the GPU box)
+# -> time of the list kernels per SPH_ABLATE variant (5: no entry loop, 0: production)
 mkdir -p gpurun_out
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-for A in ${1:-4 5 0}; do
+for A in ${1:-5 0}; do
   SPH_HIPCC_EXTRA="-DSPH_ABLATE=$A $2" python -m sphfluidsimulation_amd.build --force > /dev/null 2>&1
   echo "ABLATE=$A $2"
   timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/abl_$A -- python3 bench.py --steps 4 --warmup 3 --no-cpu-baseline > gpurun_out/abl_$A.log 2>&1 || exit 1

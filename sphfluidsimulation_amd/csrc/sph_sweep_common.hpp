@@ -141,19 +141,12 @@ __device__ __forceinline__ Pos3 integrate_store(const Dev &d, uint32_t s, float 
         vow = viw + 1.0f;
     }
     const Pos3 pn{clamp01(pix + d.dt * vox), clamp01(piy + d.dt * voy), clamp01(piz + d.dt * voz)};  // :153-154
-#if defined(SPH_ABLATE) && SPH_ABLATE == 11
-    d.nxt.vw[s] = pn.x + pn.y + pn.z + vox + voy + voz + vow;
-#elif defined(SPH_ABLATE) && SPH_ABLATE == 12
-    d.nxt.rv[s] = make_float4(rho_i, vox, voy, voz);
-    d.nxt.vw[s] = pn.x + pn.y + pn.z + vow;
-#else
     d.nxt.x[s] = pn.x;
     d.nxt.y[s] = pn.y;
     d.nxt.z[s] = pn.z;
     if (d.nxt.p4) d.nxt.p4[s] = make_float4(pn.x, pn.y, pn.z, 0.0f);
     d.nxt.rv[s] = make_float4(rho_i, vox, voy, voz);                             // :156 (+ rho rides along)
     d.nxt.vw[s] = vow;
-#endif
     if (is_wild(vox) || is_wild(voy) || is_wild(voz)) d.counters[kCntWildV0 + (d.wild_v_cur ^ 1)] = 1ull;
     return pn;
 }
