@@ -144,18 +144,35 @@ def test_gpu_mesh_properties_weird_inputs_and_errors():
 
 @pytest.mark.gpu
 def test_gpu_mesh_properties_zero_copy_export():
-    """Row f4: the render-feed buffer as a dma-buf file descriptor.  Imported again through the HIP runtime itself
-    (hipMemImportFromShareableHandle + a second mapping -- what a Vulkan importer does with VK_KHR_external_memory_fd),
-    the mapping shows the records without any copy by this library, including those of a LATER update."""
+    """Row f4: the render-feed buffer as a dma-buf file descriptor.  A CHILD PROCESS that knows nothing of this library
+    imports the inherited fd through the HIP runtime (hipMemImportFromShareableHandle + its own mapping -- what a
+    Vulkan importer does with VK_KHR_external_memory_fd) and sees the records, including those of a LATER update,
+    without any copy made by this library."""
     import ctypes as C
     import os
+    import subprocess
+    import sys
     from sphfluidsimulation_amd.simulation import SphFluidSimulation
     from sphfluidsimulation_amd import _native as N
     n = 16384
     pos0, vel0 = presets.dam_break(n, 0.8, seed=8, jitter=0.3)
     vel0[:, :3] = np.random.default_rng(2).standard_normal((n, 3)).astype(f32) * f32(0.2)
     sim = SphFluidSimulation(particleNumber=n, bucketResolution=19, damFillRate=0.8).Start(pos0, vel0)
-    hip = C.CDLL("libamdhip64.so")
+    child = os.path.join(os.path.dirname(os.path.abspath(__file__)), "import_fd_child.py")
+
+    def checksum(a):
+        u = _bits(a).reshape(-1)
+        return int(u.astype(np.uint64).sum()), int(np.bitwise_xor.reduce(u))
+
+    def seen_by_child(fd, size):
+        sim.synchronize()
+        env = {k: v for k, v in os.environ.items() if k != "PYTHONPATH"}
+        r = subprocess.run([sys.executable, child, str(fd), str(size), str(n * 80)], pass_fds=(fd,), env=env,
+                           capture_output=True, text=True, timeout=300)
+        line = [l for l in r.stdout.splitlines() if l.startswith(("CHECKSUM", "FAIL"))]
+        assert r.returncode == 0 and line and line[0].startswith("CHECKSUM"), (r.returncode, r.stdout[-500:], r.stderr[-500:])
+        return tuple(int(x) for x in line[0].split()[1:])
+
     try:
         sim.UpdateMeshProperties()
         before = sim.download_mesh_properties()
@@ -165,35 +182,12 @@ def test_gpu_mesh_properties_zero_copy_export():
             pytest.skip("no exportable device memory on this system: " + N.lib().sph_last_error(sim._ctx).decode())
         assert rc == 0 and fd.value >= 0 and size.value >= n * 80
         assert np.array_equal(_bits(sim.download_mesh_properties()), _bits(before))      # survived the move
-
-        class Loc(C.Structure):
-            _fields_ = [("type", C.c_int), ("id", C.c_int)]
-
-        class Acc(C.Structure):
-            _fields_ = [("location", Loc), ("flags", C.c_int)]
-
-        handle, va = C.c_void_p(), C.c_void_p()
-        assert hip.hipMemImportFromShareableHandle(C.byref(handle), C.c_void_p(fd.value), 1) == 0     # PosixFileDescriptor
-        assert hip.hipMemAddressReserve(C.byref(va), C.c_size_t(size.value), C.c_size_t(0), None, C.c_ulonglong(0)) == 0
-        assert hip.hipMemMap(va, C.c_size_t(size.value), C.c_size_t(0), handle, C.c_ulonglong(0)) == 0
-        acc = Acc(Loc(1, 0), 3)                                                                          # device 0, read-write
-        assert hip.hipMemSetAccess(va, C.c_size_t(size.value), C.byref(acc), C.c_size_t(1)) == 0
-
-        def read_import():
-            out = np.empty((n, 20), f32)
-            sim.synchronize()
-            assert hip.hipMemcpy(out.ctypes.data_as(C.c_void_p), va, C.c_size_t(n * 80), 2) == 0        # DeviceToHost
-            return out
-
-        assert np.array_equal(_bits(read_import()), _bits(before))
+        assert seen_by_child(fd.value, size.value) == checksum(before)
         sim.Update(1 / 600)
         sim.UpdateMeshProperties()                   # writes into the exported memory
         after = sim.download_mesh_properties()
-        assert not np.array_equal(_bits(after), _bits(before))
-        assert np.array_equal(_bits(read_import()), _bits(after))
-        assert hip.hipMemUnmap(va, C.c_size_t(size.value)) == 0
-        hip.hipMemAddressFree(va, C.c_size_t(size.value))
-        hip.hipMemRelease(handle)
+        assert checksum(after) != checksum(before)
+        assert seen_by_child(fd.value, size.value) == checksum(after)
         os.close(fd.value)
     finally:
         sim.OnDestroy()
