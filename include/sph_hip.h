@@ -74,6 +74,7 @@ typedef struct SphParams {
 #define SPH_FLAG_PROFILE 1u     /* record HIP events around every pass (SphStats.ms_*)            */
 #define SPH_FLAG_NO_TILING 2u   /* diagnostic: per-target kernels on global memory, no LDS bricks */
 #define SPH_FLAG_NO_LISTS 4u    /* diagnostic: every sub-step re-scans its 27 bins (no frame-coherent neighbour lists) */
+#define SPH_FLAG_NO_GRAPHS 8u   /* diagnostic: sph_step issues its ~60 launches every frame instead of replaying a HIP graph */
 
 /* Values of the uniforms the reference pushes through ShaderIDs.cs:5-32. */
 typedef struct SphDerived {
@@ -113,6 +114,7 @@ typedef struct SphStats {
     uint64_t list_entries;            /* list entries those target sub-steps walked                        */
     double ms_velpos_list;            /* GPU time of k_velpos_list alone (part of ms_velpos), SPH_FLAG_PROFILE */
     uint64_t launches_velpos_list;
+    uint64_t graph_replays;           /* sph_step frames replayed from a captured HIP graph since create         */
 } SphStats;
 
 typedef struct SphContext SphContext;

@@ -18,6 +18,7 @@ SPH_E_COMM = -6
 SPH_FLAG_PROFILE = 1
 SPH_FLAG_NO_TILING = 2
 SPH_FLAG_NO_LISTS = 4
+SPH_FLAG_NO_GRAPHS = 8
 SPH_SLAB_UPDATE_RHO = 0
 SPH_SLAB_UPDATE_POSVEL = 1
 SPH_SLAB_RECORD_WORDS = 9
@@ -93,6 +94,7 @@ class SphStats(C.Structure):
         ("list_entries", C.c_uint64),
         ("ms_velpos_list", C.c_double),
         ("launches_velpos_list", C.c_uint64),
+        ("graph_replays", C.c_uint64),
     ]
 
     def as_dict(self):

@@ -33,6 +33,21 @@ struct SphContext {
     // staging in the reference's texture layout
     float4 *pos4_dev = nullptr, *vel4_dev = nullptr;
     float *rho_id_dev = nullptr, *pw0 = nullptr;
+    // One frame (grid build, density pass, S sub-steps: ~60 launches) captured as a HIP graph and replayed: for scenes of the
+    // reference's own size (262 144 particles, ~2 ms per frame) the launches cost as much as a third of the frame.
+    // The device pointers a frame starts from alternate with period 2 (id / id_nxt and the wild-velocity slot flip once per
+    // frame), so there are two graphs; each remembers the launch state (Dev) it was captured for and is re-captured when
+    // that no longer matches (sph_set_params, another sub-step count).  delta_time is read from device memory.
+    struct FrameGraph {
+        hipGraphExec_t exec = nullptr;
+        Dev start{};                  // launch state at frame start
+        uint32_t substeps = 0;
+        bool recorded_lists = false;  // the captured density pass recorded neighbour lists
+        bool lists_on = false;        // neighbour lists were enabled and allocated at capture time
+    } graph[2];
+    bool graphs_enabled = false;
+    float *dt_dev = nullptr;          // delta_time / dt_divisor of the frame being replayed (device scalar)
+    uint64_t frames_since_upload = 0, graph_replays = 0;
     // frame-coherent neighbour lists (sph_kernels_list.hip)
     bool nl_enabled = false, nl_allocated = false;
     bool nl_fresh = false;            // the grid was just built: the next density pass runs on the binned positions
@@ -445,6 +460,8 @@ static int create_common(const SphParams *params, uint32_t capacity, bool slab, 
     A(dalloc(c, &d.queue, n));
     A(dalloc(c, &d.counters, (size_t)kCntCount));
     A(dalloc(c, &d.stripes, (size_t)kStatCount * kStatStripes * kStatPad));
+    A(dalloc(c, &c->dt_dev, (size_t)1));
+    c->graphs_enabled = !slab && !c->profile && !(params->flags & SPH_FLAG_NO_GRAPHS);
     A(dalloc(c, &c->pos4_dev, n));
     A(dalloc(c, &c->vel4_dev, n));
     A(dalloc(c, &c->rho_id_dev, n));
@@ -491,6 +508,8 @@ int sph_destroy(SphContext *c)
     fold_events(c);
     for (hipEvent_t e : c->free_events) (void)hipEventDestroy(e);
     for (void *p : c->allocs) (void)hipFree(p);
+    for (auto &g : c->graph)
+        if (g.exec) (void)hipGraphExecDestroy(g.exec);
     if (c->mesh_va) {
         (void)hipMemUnmap(c->mesh_va, c->mesh_va_size);
         (void)hipMemAddressFree(c->mesh_va, c->mesh_va_size);
@@ -520,6 +539,7 @@ int sph_upload(SphContext *c, const float *pos4, const float *vel4)
     c->grid_valid = false;
     c->mesh_valid = false;
     c->substeps_since_upload = 0;
+    c->frames_since_upload = 0;
     return SPH_OK;
 }
 
@@ -545,6 +565,7 @@ int sph_init_particles(SphContext *c, int preset)
     c->grid_valid = false;
     c->mesh_valid = false;
     c->substeps_since_upload = 0;
+    c->frames_since_upload = 0;
     return SPH_OK;
 }
 
@@ -677,7 +698,36 @@ int sph_update_velocity_and_position(SphContext *c, float dt)
 {
     if (!c) return fail(nullptr, SPH_E_INVALID_ARG, "ctx is NULL");
     HIP_TRY(c, hipSetDevice(c->device));
+    c->dev.dt_ptr = nullptr;          // dt travels by value here (a replayed frame graph reads it from device memory)
     return do_velpos(c, dt);
+}
+
+// The launches of one Update() (SphFluidSimulation.cs:96-102), issued on the context's stream.
+static int issue_frame(SphContext *c, float dt)
+{
+    int rc;
+    if ((rc = do_bucket_generation(c)) != SPH_OK) return rc;            // :98
+    if ((rc = do_density(c)) != SPH_OK) return rc;                      // :99
+    for (uint32_t i = 0; i < c->params.substeps; i++)                   // :101
+        if ((rc = do_velpos(c, dt)) != SPH_OK) return rc;
+    return SPH_OK;
+}
+
+// Host-side state a replayed frame leaves behind (what issue_frame's passes would have set).
+static void account_replayed_frame(SphContext *c, const SphContext::FrameGraph &g, float dt)
+{
+    const uint32_t S = c->params.substeps;
+    std::swap(c->dev.id, c->dev.id_nxt);                                // the grid build's swaps; cur/nxt: 1 + S swaps
+    if ((1u + S) & 1u) std::swap(c->dev.cur, c->dev.nxt);
+    if (S & 1u) c->dev.wild_v_cur ^= 1u;
+    c->dev.force_slow = 0;
+    c->grid_valid = true;
+    c->nl_fresh = false;
+    c->nl_recorded = g.recorded_lists;
+    c->frames++;
+    c->substeps += S;
+    c->substeps_since_upload += (int)S;
+    c->dt_last = dt;
 }
 
 int sph_step(SphContext *c, float delta_time)
@@ -685,12 +735,61 @@ int sph_step(SphContext *c, float delta_time)
     if (!c) return fail(nullptr, SPH_E_INVALID_ARG, "ctx is NULL");
     if (c->slab) return fail(c, SPH_E_BAD_STATE, "slab context: the host drives the passes and the halo exchange");
     HIP_TRY(c, hipSetDevice(c->device));
-    int rc;
-    if ((rc = do_bucket_generation(c)) != SPH_OK) return rc;            // :98
-    if ((rc = do_density(c)) != SPH_OK) return rc;                      // :99
     const float dt = delta_time / c->params.dt_divisor;                 // :102 Time.deltaTime / 25
-    for (uint32_t i = 0; i < c->params.substeps; i++)                   // :101
-        if ((rc = do_velpos(c, dt)) != SPH_OK) return rc;
+    // the first two frames after an upload run ungraphed: they allocate (neighbour lists) and settle the pointer parity
+    const bool graphed = c->graphs_enabled && c->own_stream && c->uploaded && c->frames_since_upload >= 2 && c->params.substeps > 0;
+    c->frames_since_upload++;
+    if (!graphed) {
+        c->dev.dt_ptr = nullptr;
+        return issue_frame(c, dt);
+    }
+    SphContext::FrameGraph &g = c->graph[c->frames_since_upload & 1u];
+    launch_set_scalar(c->dt_dev, dt, c->stream);
+    c->dev.dt_ptr = c->dt_dev;
+    c->dev.dt = 0.0f;
+    Dev start;                        // (memcpy: the comparison below is bytewise, padding included)
+    memcpy(&start, &c->dev, sizeof(Dev));
+    start.nl_mode = 0;                // per-launch scratch
+    start.nl_still = 0;
+    const bool lists_on = c->nl_enabled && c->nl_allocated;
+    if (!g.exec || g.substeps != c->params.substeps || g.lists_on != lists_on || memcmp(&g.start, &start, sizeof(Dev)) != 0) {
+        if (g.exec) (void)hipGraphExecDestroy(g.exec);
+        g.exec = nullptr;
+        hipGraph_t graph = nullptr;
+        Dev dev_before;
+        memcpy(&dev_before, &c->dev, sizeof(Dev));
+        const bool grid_valid = c->grid_valid, fresh = c->nl_fresh, recorded = c->nl_recorded;
+        const uint64_t frames = c->frames, substeps = c->substeps;
+        const int since = c->substeps_since_upload;
+        bool ok = hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
+        int rc = ok ? issue_frame(c, dt) : SPH_OK;
+        if (ok) ok = hipStreamEndCapture(c->stream, &graph) == hipSuccess && graph && rc == SPH_OK;
+        if (ok) ok = hipGraphInstantiate(&g.exec, graph, nullptr, nullptr, 0) == hipSuccess;
+        if (graph) (void)hipGraphDestroy(graph);
+        g.recorded_lists = c->nl_recorded;
+        // nothing has run yet: roll the host-side bookkeeping back to the frame start, the replay below redoes it
+        memcpy(&c->dev, &dev_before, sizeof(Dev));
+        c->grid_valid = grid_valid;
+        c->nl_fresh = fresh;
+        c->nl_recorded = recorded;
+        c->frames = frames;
+        c->substeps = substeps;
+        c->substeps_since_upload = since;
+        if (!ok) {                    // no graphs on this system / for this launch sequence: keep issuing the launches
+            (void)hipGetLastError();
+            if (g.exec) (void)hipGraphExecDestroy(g.exec);
+            g.exec = nullptr;
+            c->graphs_enabled = false;
+            c->dev.dt_ptr = nullptr;
+            return issue_frame(c, dt);
+        }
+        memcpy(&g.start, &start, sizeof(Dev));
+        g.substeps = c->params.substeps;
+        g.lists_on = lists_on;
+    }
+    HIP_TRY(c, hipGraphLaunch(g.exec, c->stream));
+    c->graph_replays++;
+    account_replayed_frame(c, g, dt);
     return SPH_OK;
 }
 
@@ -758,6 +857,7 @@ int sph_get_stats(SphContext *c, SphStats *out)
     out->launches_grid = c->launches[0];
     out->launches_density = c->launches[1];
     out->launches_velpos = c->launches[2];
+    out->graph_replays = c->graph_replays;
     out->ms_velpos_list = c->ms[3];
     out->launches_velpos_list = c->launches[3];
     out->max_cell_occupancy = (uint32_t)cnt[kCntMaxOcc];
@@ -854,6 +954,7 @@ int sph_slab_upload(SphContext *c, uint32_t n, const float *pos4, const float *v
     c->grid_valid = false;
     c->mesh_valid = false;
     c->substeps_since_upload = 0;
+    c->frames_since_upload = 0;
     c->n_ghost[0] = c->n_ghost[1] = c->n_export[0] = c->n_export[1] = 0;
     return SPH_OK;
 }

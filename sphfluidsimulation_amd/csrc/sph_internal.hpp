@@ -31,7 +31,8 @@ struct Dev {
     float c_over_h6;       // (45/pi)/h^6           VelPos.compute:37,43
     float viscosity, gas_const, rest_density, stiffness, damping;
     float gx, gy, gz;
-    float dt;
+    float dt;              // sub-step length, by value ... 
+    const float *dt_ptr;   // ... or, when a captured frame graph is replayed with another delta_time, read from here
     uint32_t force_slow;   // 1: take the literal one-phase VelPos loop (set by sph_set_params)
     uint32_t wild_v_cur;   // which kCntWildV slot describes the velocities in `cur`
     uint32_t use_bricks;   // 1: LDS-tiled brick kernels + queue; 0: per-target kernels on global memory
@@ -155,6 +156,7 @@ __device__ __forceinline__ int cell_coord(float p, float Rm1, int R)
 void launch_upload_split(const Dev &d, const float4 *pos4, const float4 *vel4, float *pw0, hipStream_t s);
 void launch_download_merge(const Dev &d, const float *pw0, int substeps_done, float dt_last,
                            float4 *pos4, float4 *vel4, float *rho_by_id, hipStream_t s);
+void launch_set_scalar(float *p, float v, hipStream_t s);
 void launch_grid_build(const Dev &d, hipStream_t s);  // keys, histogram, scan, scatter, id-sort, reorder: cur -> nxt
 void launch_density(const Dev &d, hipStream_t s);     // sph_kernels_brick.hip (tiled) + queue
 // cur -> nxt; the optional events bracket k_velpos_list (recorded only in a sub-step that uses neighbour lists)

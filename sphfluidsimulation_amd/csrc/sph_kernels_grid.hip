@@ -271,7 +271,12 @@ __global__ void __launch_bounds__(kBlock) k_reorder(Dev d)
     }
 }
 
+// one float into device memory, the value travelling in the launch packet (no host staging buffer to race with)
+__global__ void k_set_scalar(float *p, float v) { *p = v; }
+
 // ---- launchers ---------------------------------------------------------------------------------
+
+void launch_set_scalar(float *p, float v, hipStream_t s) { hipLaunchKernelGGL(k_set_scalar, dim3(1), dim3(1), 0, s, p, v); }
 
 static inline uint32_t cdiv(uint32_t a, uint32_t b) { return a ? (a + b - 1) / b : 1u; }  // never an empty grid
 

@@ -102,6 +102,7 @@ __device__ __forceinline__ Pos3 integrate_store(const Dev &d, uint32_t s, float 
 {
     const float epsilon = 1e-6f;
     const float h = d.h, m = d.mass;
+    const float dt = d.dt_ptr ? *d.dt_ptr : d.dt;
     if (rho_i > epsilon) {                                                       // :101
         const float sp = m * m / rho_i;                                          // :103
         f.px *= sp; f.py *= sp; f.pz *= sp;
@@ -135,12 +136,12 @@ __device__ __forceinline__ Pos3 integrate_store(const Dev &d, uint32_t s, float 
         vox = 0.0f; voy = 0.0f; voz = 0.0f; vow = 0.003f;                        // :145-146
         atomicAdd(&d.counters[kCntNaN], 1ull);
     } else {
-        vox = vix + ax * d.dt;                                                   // :150
-        voy = viy + ay * d.dt;
-        voz = viz + az * d.dt;
+        vox = vix + ax * dt;                                                   // :150
+        voy = viy + ay * dt;
+        voz = viz + az * dt;
         vow = viw + 1.0f;
     }
-    const Pos3 pn{clamp01(pix + d.dt * vox), clamp01(piy + d.dt * voy), clamp01(piz + d.dt * voz)};  // :153-154
+    const Pos3 pn{clamp01(pix + dt * vox), clamp01(piy + dt * voy), clamp01(piz + dt * voz)};  // :153-154
     d.nxt.x[s] = pn.x;
     d.nxt.y[s] = pn.y;
     d.nxt.z[s] = pn.z;

@@ -28,7 +28,7 @@ class SphFluidSimulation:
                  damFillRate: float = 0.5, viscosity: float = 0.01, restDensity: float = 1.5,
                  gasConstant: float = 150.0, stiffnessCoefficient: float = 5000.0,
                  dampingCoefficient: float = 10.0, device_id: int = 0, profile: bool = False,
-                 tiling: bool = True, lists: bool = True, particleRadius: float = 0.01, lowSpeed: float = 0.0,
+                 tiling: bool = True, lists: bool = True, graphs: bool = True, particleRadius: float = 0.01, lowSpeed: float = 0.0,
                  highSpeed: float = 0.5):
         # inspector fields and defaults, SphFluidSimulation.cs:35-45
         self.preset = preset
@@ -48,6 +48,7 @@ class SphFluidSimulation:
         self.profile = profile
         self.tiling = tiling            # False: diagnostic per-target kernels (SPH_FLAG_NO_TILING)
         self.lists = lists              # False: every sub-step re-scans its 27 bins (SPH_FLAG_NO_LISTS)
+        self.graphs = graphs            # False: no HIP-graph replay of whole frames (SPH_FLAG_NO_GRAPHS)
         self._ctx = C.c_void_p()
         self._derived = None
 
@@ -64,7 +65,7 @@ class SphFluidSimulation:
         p.damping_coeff = self.dampingCoefficient
         p.device_id = self.device_id
         p.flags = ((N.SPH_FLAG_PROFILE if self.profile else 0) | (0 if self.tiling else N.SPH_FLAG_NO_TILING) |
-                   (0 if self.lists else N.SPH_FLAG_NO_LISTS))
+                   (0 if self.lists else N.SPH_FLAG_NO_LISTS) | (0 if self.graphs else N.SPH_FLAG_NO_GRAPHS))
         return p
 
     def _check(self, rc):
