@@ -68,12 +68,12 @@ __global__ void __launch_bounds__(kBlock) k_chunk_box(Dev d)
 // runs touch bound |delta_i - delta_j| for a target i of the brick and any j in its recorded stencil (one cell away,
 // condition 1) or in a bin that may enter its stencil (two cells away, condition 2).
 // calm <=> every target of the brick has its list and the Euclidean bound rho <= skin_ok.
-__global__ void __launch_bounds__(kBlock) k_brick_activity(Dev d, int nbx, int nby, int n_bricks)
+__global__ void __launch_bounds__(kBlock) k_brick_activity(Dev d, int nbx, int nby, int first, int n_bricks)
 {
     __shared__ uint32_t s_act[2];
-    const int b_raw = blockIdx.x * (kBlock / kWave) + threadIdx.x / kWave, lane = threadIdx.x & (kWave - 1), R = (int)d.R;
-    const bool exists = b_raw < n_bricks;          // wave-uniform
-    const int b = exists ? b_raw : n_bricks - 1;
+    const int b_raw = first + blockIdx.x * (kBlock / kWave) + threadIdx.x / kWave, lane = threadIdx.x & (kWave - 1), R = (int)d.R;
+    const bool exists = b_raw < first + n_bricks;  // wave-uniform; the launch covers the brick layers that hold targets
+    const int b = exists ? b_raw : first + n_bricks - 1;
     const bool blocked = nl_blocked(d);            // then the scanning kernel takes every brick
     if (threadIdx.x == 0) s_act[0] = 0;
     __syncthreads();
@@ -351,8 +351,13 @@ void launch_list_prepare(const Dev &d, hipStream_t s)
     const uint32_t nbx = nl_bricks_x(d.R), nby = nl_bricks_y(d.R), nbz = nl_bricks_z(d.R);
     (void)hipMemsetAsync(d.counters + kCntActiveCount, 0, sizeof(unsigned long long), s);
     if (!d.nl_still) hipLaunchKernelGGL(k_chunk_box, dim3(cdiv(d.count, kBlock)), dim3(kBlock), 0, s, d);
-    hipLaunchKernelGGL(k_brick_activity, dim3(cdiv(nbx * nby * nbz, kBlock / kWave)), dim3(kBlock), 0, s, d, (int)nbx,
-                       (int)nby, (int)(nbx * nby * nbz));
+    // the brick layers along z with planes that hold targets (z-slab mode: this rank's planes)
+    const int zl = d.zo_lo < 0 ? 0 : d.zo_lo, zh = d.zo_hi > (int)d.R ? (int)d.R : d.zo_hi;
+    const uint32_t bl = (uint32_t)zl / kNlBZ, bh = zh > zl ? ((uint32_t)zh + kNlBZ - 1) / kNlBZ : bl;
+    const uint32_t count = nbx * nby * ((bh < nbz ? bh : nbz) - bl);
+    if (count)
+        hipLaunchKernelGGL(k_brick_activity, dim3(cdiv(count, kBlock / kWave)), dim3(kBlock), 0, s, d, (int)nbx, (int)nby,
+                           (int)(nbx * nby * bl), (int)count);
 }
 
 void launch_velpos_lists(const Dev &d, hipStream_t s)
