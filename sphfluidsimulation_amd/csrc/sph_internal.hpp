@@ -162,7 +162,7 @@ void launch_density(const Dev &d, hipStream_t s);     // sph_kernels_brick.hip (
 // cur -> nxt; the optional events bracket k_velpos_list (recorded only in a sub-step that uses neighbour lists)
 void launch_velpos(const Dev &d, hipStream_t s, hipEvent_t list_begin = nullptr, hipEvent_t list_end = nullptr);
 void launch_list_prepare(const Dev &d, hipStream_t s);  // sph_kernels_list.hip: which bricks may use their lists
-void launch_velpos_lists(const Dev &d, hipStream_t s);  // sph_kernels_list.hip: the targets of those bricks, cur -> nxt
+void launch_velpos_lists(const Dev &d, hipStream_t s, hipEvent_t list_begin = nullptr, hipEvent_t list_end = nullptr);  // sph_kernels_list.hip: the targets of those bricks, cur -> nxt
 
 
 // row f1: InitParticles.compute presets on the device (sph_kernels_init.hip)

@@ -360,10 +360,12 @@ void launch_list_prepare(const Dev &d, hipStream_t s)
                            (int)(nbx * nby * bl), (int)count);
 }
 
-void launch_velpos_lists(const Dev &d, hipStream_t s)
+void launch_velpos_lists(const Dev &d, hipStream_t s, hipEvent_t list_begin, hipEvent_t list_end)
 {
     (void)hipMemsetAsync(d.counters + kCntQueue2, 0, sizeof(unsigned long long), s);
+    if (list_begin) (void)hipEventRecord(list_begin, s);     // the events bracket k_velpos_list alone (bench.py roofline)
     hipLaunchKernelGGL(k_velpos_list, dim3(cdiv(d.count, kBlock)), dim3(kBlock), 0, s, d);
+    if (list_end) (void)hipEventRecord(list_end, s);
     const uint32_t g = cdiv(d.count, kBlock);
     hipLaunchKernelGGL(k_velpos_list_changers, dim3(g < 1024u ? g : 1024u), dim3(kBlock), 0, s, d);
 }
