@@ -180,3 +180,31 @@ def test_frame_graph_replay_matches_issued_launches(oracle):
     finally:
         for s in sims:
             s.OnDestroy()
+
+
+def test_one_million_particles_six_frames(oracle):
+    """A mid-size end-to-end run the way a Unity caller would drive it: the reference's own initial condition on the
+    device (InitParticles.compute Preset1 + simplex noise), six sph_step frames (lists from frame 2, graph replay from
+    frame 3), render feed at the end -- everything bit-identical to the oracle."""
+    from sphfluidsimulation_amd.simulation import SphFluidSimulation
+    n, fill = 1048576, 0.8
+    R = presets.scene_bucket_resolution(n)
+    dt = presets.bench_dt_frame(R)
+    sim = SphFluidSimulation(preset=0, particleNumber=n, bucketResolution=R, damFillRate=fill).Start(seed=None)
+    osim = oracle.OracleSimulation(oracle.derive(n, R, fill))
+    osim.upload(oracle.init_particles(0, 1024, fill), np.zeros((n, 4), f32))
+    try:
+        for _ in range(6):
+            sim.Update(dt)
+            osim.Update(dt)
+        got, want = sim.download(), osim.download()
+        for a, b in zip(got, want):
+            assert np.array_equal(_bits(a), _bits(b))
+        st = sim.stats()
+        assert st["listed_target_substeps"] > 0.3 * n * 5 * 5 and st["graph_replays"] == 4   # (a 1M box is still mostly wall layer)
+        sim.UpdateMeshProperties()
+        props = sim.download_mesh_properties()
+        assert np.array_equal(_bits(props), _bits(oracle.update_mesh_properties(want[0], want[1], sim.lowSpeed, sim.highSpeed,
+                                                                               sim.particleRadius)))
+    finally:
+        sim.OnDestroy()
