@@ -74,6 +74,8 @@ typedef struct SphParams {
 #define SPH_FLAG_PROFILE 1u     /* record HIP events around every pass (SphStats.ms_*)            */
 #define SPH_FLAG_NO_TILING 2u   /* diagnostic: per-target kernels on global memory, no LDS bricks */
 #define SPH_FLAG_NO_LISTS 4u    /* diagnostic: every sub-step re-scans its 27 bins (no frame-coherent neighbour lists) */
+#define SPH_FLAG_LISTS_ALWAYS 16u /* diagnostic: record neighbour lists every frame (default: only while they pay, see
+                                    SphStats.frames_without_lists) */
 #define SPH_FLAG_NO_GRAPHS 8u   /* diagnostic: sph_step issues its ~60 launches every frame instead of replaying a HIP graph */
 
 /* Values of the uniforms the reference pushes through ShaderIDs.cs:5-32. */
@@ -115,6 +117,7 @@ typedef struct SphStats {
     double ms_velpos_list;            /* GPU time of k_velpos_list alone (part of ms_velpos), SPH_FLAG_PROFILE */
     uint64_t launches_velpos_list;
     uint64_t graph_replays;           /* sph_step frames replayed from a captured HIP graph since create         */
+    uint64_t frames_without_lists;    /* sph_step frames the list policy ran without recording (lists would not pay) */
 } SphStats;
 
 typedef struct SphContext SphContext;

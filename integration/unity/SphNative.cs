@@ -52,7 +52,7 @@ public static class SphNative
         public ulong nan_resets, candidates_density, halo_violations;
         public ulong listed_target_substeps, scanned_brick_substeps, list_entries;
         public double ms_velpos_list;
-        public ulong launches_velpos_list, graph_replays;
+        public ulong launches_velpos_list, graph_replays, frames_without_lists;
     }
 
     [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int sph_version();

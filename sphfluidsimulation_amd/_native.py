@@ -19,6 +19,7 @@ SPH_FLAG_PROFILE = 1
 SPH_FLAG_NO_TILING = 2
 SPH_FLAG_NO_LISTS = 4
 SPH_FLAG_NO_GRAPHS = 8
+SPH_FLAG_LISTS_ALWAYS = 16
 SPH_SLAB_UPDATE_RHO = 0
 SPH_SLAB_UPDATE_POSVEL = 1
 SPH_SLAB_RECORD_WORDS = 9
@@ -95,6 +96,7 @@ class SphStats(C.Structure):
         ("ms_velpos_list", C.c_double),
         ("launches_velpos_list", C.c_uint64),
         ("graph_replays", C.c_uint64),
+        ("frames_without_lists", C.c_uint64),
     ]
 
     def as_dict(self):

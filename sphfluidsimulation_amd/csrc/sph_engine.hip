@@ -52,6 +52,22 @@ struct SphContext {
     bool nl_enabled = false, nl_allocated = false;
     bool nl_fresh = false;            // the grid was just built: the next density pass runs on the binned positions
     bool nl_recorded = false;         // ... and recorded the lists the VelPos sub-steps of this frame may use
+    // List policy.  Recording lists and keeping them valid costs ~25 % of a scanning frame at 16.7 M -- where 99 % of the
+    // target sub-steps are then served three times faster -- but makes a frame of the reference's own 262 144-particle
+    // scene 1.5x slower (a box that small is all wall layer, 28 % served; its kernels are latency-bound, every extra
+    // launch counts).  k_frame_report publishes, frame by frame, how many target sub-steps the lists served; below 90 %
+    // (two reports in a row) the engine stops recording and probes again after a back-off that doubles with every
+    // failed probe.
+    volatile unsigned long long *report_host = nullptr;   // mapped pinned memory, written by the device
+    unsigned long long *report_dev = nullptr;
+    unsigned long long pol_seen[3] = {0, 0, 0};
+    bool pol_on = true;               // this frame records lists
+    bool pol_confirmed = false;       // two good reports since recording was (re)started: until then the host does not run
+                                      // more than two frames ahead of the reports (a caller queueing 20 frames would
+                                      // otherwise pay for 20 frames of a probe that fails)
+    unsigned long long pol_issued = 0;   // frames issued with a report kernel
+    int pol_low_streak = 0, pol_high_streak = 0;
+    uint64_t pol_backoff = 8, pol_resume_at = 0, pol_frames_off = 0;
     float nl_skin_frac = 0.04f;       // skin / h (profiles/: 0.04-0.06 is the optimum of the 16.7 M dam break)
     float4 *mesh_props = nullptr;     // _particleMeshPropertiesBuffer (:174), allocated on first use
     bool mesh_valid = false;
@@ -80,6 +96,19 @@ struct SphContext {
     uint32_t *slab_counters = nullptr;  // 4 words, see k_slab_classify
     uint32_t *ids_dev = nullptr;
 };
+
+// A new particle set: the list policy starts over.  Prior: in a box of fewer than ~100 cells per axis most bricks lie
+// within reach of the wall layer, whose particles the wall force scatters by more than any useful skin -- such scenes
+// start without lists and probe late; large boxes start with lists.
+static void reset_list_policy(SphContext *c)
+{
+    const bool big = c->dev.R >= 100u;
+    c->pol_on = big || (c->params.flags & SPH_FLAG_LISTS_ALWAYS);
+    c->pol_confirmed = false;
+    c->pol_low_streak = c->pol_high_streak = 0;
+    c->pol_backoff = big ? 8 : 32;
+    c->pol_resume_at = c->frames + (c->pol_on ? 0 : c->pol_backoff);
+}
 
 static int fail(SphContext *ctx, int code, const char *fmt, ...)
 {
@@ -308,8 +337,8 @@ static void ensure_lists(SphContext *c)
 static int do_bucket_generation(SphContext *c)
 {
     if (!c->uploaded) return fail(c, SPH_E_BAD_STATE, "BucketGeneration before sph_upload");
-    ensure_lists(c);
-    c->dev.use_lists = c->nl_enabled && c->nl_allocated ? 1u : 0u;
+    if (c->pol_on) ensure_lists(c);   // (several GB at 16.7 M: only once a frame is going to record)
+    c->dev.use_lists = c->nl_enabled && c->nl_allocated && c->pol_on ? 1u : 0u;
     c->nl_fresh = c->dev.use_lists != 0u;
     c->nl_recorded = false;
     {
@@ -462,6 +491,18 @@ static int create_common(const SphParams *params, uint32_t capacity, bool slab, 
     A(dalloc(c, &d.stripes, (size_t)kStatCount * kStatStripes * kStatPad));
     A(dalloc(c, &c->dt_dev, (size_t)1));
     c->graphs_enabled = !slab && !c->profile && !(params->flags & SPH_FLAG_NO_GRAPHS);
+    {
+        void *h = nullptr, *dv = nullptr;
+        if (hipHostMalloc(&h, 4 * sizeof(unsigned long long), hipHostMallocMapped) == hipSuccess &&
+            hipHostGetDevicePointer(&dv, h, 0) == hipSuccess) {
+            memset(h, 0, 4 * sizeof(unsigned long long));
+            c->report_host = (volatile unsigned long long *)h;
+            c->report_dev = (unsigned long long *)dv;
+        } else {
+            (void)hipGetLastError();
+            if (h) (void)hipHostFree(h);
+        }
+    }
     A(dalloc(c, &c->pos4_dev, n));
     A(dalloc(c, &c->vel4_dev, n));
     A(dalloc(c, &c->rho_id_dev, n));
@@ -510,6 +551,7 @@ int sph_destroy(SphContext *c)
     for (void *p : c->allocs) (void)hipFree(p);
     for (auto &g : c->graph)
         if (g.exec) (void)hipGraphExecDestroy(g.exec);
+    if (c->report_host) (void)hipHostFree((void *)c->report_host);
     if (c->mesh_va) {
         (void)hipMemUnmap(c->mesh_va, c->mesh_va_size);
         (void)hipMemAddressFree(c->mesh_va, c->mesh_va_size);
@@ -540,6 +582,7 @@ int sph_upload(SphContext *c, const float *pos4, const float *vel4)
     c->mesh_valid = false;
     c->substeps_since_upload = 0;
     c->frames_since_upload = 0;
+    reset_list_policy(c);
     return SPH_OK;
 }
 
@@ -566,6 +609,7 @@ int sph_init_particles(SphContext *c, int preset)
     c->mesh_valid = false;
     c->substeps_since_upload = 0;
     c->frames_since_upload = 0;
+    reset_list_policy(c);
     return SPH_OK;
 }
 
@@ -706,11 +750,58 @@ int sph_update_velocity_and_position(SphContext *c, float dt)
 static int issue_frame(SphContext *c, float dt)
 {
     int rc;
+    const bool stamped = c->report_dev && c->nl_enabled && !c->slab;
     if ((rc = do_bucket_generation(c)) != SPH_OK) return rc;            // :98
     if ((rc = do_density(c)) != SPH_OK) return rc;                      // :99
     for (uint32_t i = 0; i < c->params.substeps; i++)                   // :101
         if ((rc = do_velpos(c, dt)) != SPH_OK) return rc;
+    if (stamped) launch_frame_report(c->dev, c->report_dev, c->nl_recorded, c->stream);
     return SPH_OK;
+}
+
+static bool frame_reports(const SphContext *c) { return c->report_dev && c->nl_enabled && !c->slab; }
+
+// Decides, before a frame is issued, whether it records neighbour lists (see SphContext::pol_*).
+static void update_list_policy(SphContext *c)
+{
+    if (!c->report_host || !c->nl_enabled || c->slab || (c->params.flags & SPH_FLAG_LISTS_ALWAYS)) return;
+    if (c->pol_on && !c->pol_confirmed && c->frames_since_upload > 3 && c->pol_issued > c->report_host[0] + 2)
+        (void)hipStreamSynchronize(c->stream);   // only while a (re)start of the recording is being judged
+    const unsigned long long frames = c->report_host[0];
+    if (frames != c->pol_seen[0]) {
+        const unsigned long long listed = c->report_host[1], list_frames = c->report_host[2];
+        const unsigned long long dlf = list_frames - c->pol_seen[2];
+        if (dlf > 0 && listed >= c->pol_seen[1] && c->frames_since_upload > 3) {
+            const double frac = (double)(listed - c->pol_seen[1]) / ((double)dlf * (double)c->dev.count * (double)c->params.substeps);
+            if (c->pol_on) {
+                // (the first sub-step of a frame is always served: 0.9 of all means 0.875 of the sub-steps that can fail)
+                if (frac < 0.9) {
+                    c->pol_high_streak = 0;
+                    if (++c->pol_low_streak >= 2) {
+                        c->pol_on = false;
+                        c->pol_low_streak = 0;
+                        c->pol_resume_at = c->frames + c->pol_backoff;
+                        c->pol_backoff = c->pol_backoff < 128 ? c->pol_backoff * 2 : 128;
+                    }
+                } else {
+                    c->pol_low_streak = 0;
+                    if (++c->pol_high_streak >= 2) {
+                        c->pol_confirmed = true;
+                        c->pol_backoff = 8;
+                    }
+                }
+            }
+        }
+        c->pol_seen[0] = frames;
+        c->pol_seen[1] = listed;
+        c->pol_seen[2] = list_frames;
+    }
+    if (!c->pol_on && c->frames >= c->pol_resume_at) {   // probe: two low reports switch it off again
+        c->pol_on = true;
+        c->pol_confirmed = false;
+        c->pol_low_streak = c->pol_high_streak = 0;
+    }
+    if (!c->pol_on) c->pol_frames_off++;
 }
 
 // Host-side state a replayed frame leaves behind (what issue_frame's passes would have set).
@@ -736,6 +827,9 @@ int sph_step(SphContext *c, float delta_time)
     if (c->slab) return fail(c, SPH_E_BAD_STATE, "slab context: the host drives the passes and the halo exchange");
     HIP_TRY(c, hipSetDevice(c->device));
     const float dt = delta_time / c->params.dt_divisor;                 // :102 Time.deltaTime / 25
+    update_list_policy(c);
+    if (c->pol_on) ensure_lists(c);   // (never inside a stream capture)
+    if (frame_reports(c)) c->pol_issued++;
     // the first two frames after an upload run ungraphed: they allocate (neighbour lists) and settle the pointer parity
     const bool graphed = c->graphs_enabled && c->own_stream && c->uploaded && c->frames_since_upload >= 2 && c->params.substeps > 0;
     c->frames_since_upload++;
@@ -751,7 +845,7 @@ int sph_step(SphContext *c, float delta_time)
     memcpy(&start, &c->dev, sizeof(Dev));
     start.nl_mode = 0;                // per-launch scratch
     start.nl_still = 0;
-    const bool lists_on = c->nl_enabled && c->nl_allocated;
+    const bool lists_on = c->nl_enabled && c->nl_allocated && c->pol_on;
     if (!g.exec || g.substeps != c->params.substeps || g.lists_on != lists_on || memcmp(&g.start, &start, sizeof(Dev)) != 0) {
         if (g.exec) (void)hipGraphExecDestroy(g.exec);
         g.exec = nullptr;
@@ -858,6 +952,7 @@ int sph_get_stats(SphContext *c, SphStats *out)
     out->launches_density = c->launches[1];
     out->launches_velpos = c->launches[2];
     out->graph_replays = c->graph_replays;
+    out->frames_without_lists = c->pol_frames_off;
     out->ms_velpos_list = c->ms[3];
     out->launches_velpos_list = c->launches[3];
     out->max_cell_occupancy = (uint32_t)cnt[kCntMaxOcc];
@@ -883,6 +978,7 @@ int sph_reset_stats(SphContext *c)
         c->ms[i] = 0;
         c->launches[i] = 0;
     }
+    c->pol_seen[1] = 0;               // (the cumulative count the policy differences restarts)
     HIP_TRY(c, hipMemsetAsync(c->dev.counters + kCntActiveBricks, 0, sizeof(unsigned long long), c->stream));
     HIP_TRY(c, hipMemsetAsync(c->dev.stripes + (size_t)kStatListed * kStatStripes * kStatPad, 0,
                               2 * sizeof(unsigned long long) * kStatStripes * kStatPad, c->stream));
@@ -955,6 +1051,7 @@ int sph_slab_upload(SphContext *c, uint32_t n, const float *pos4, const float *v
     c->mesh_valid = false;
     c->substeps_since_upload = 0;
     c->frames_since_upload = 0;
+    reset_list_policy(c);
     c->n_ghost[0] = c->n_ghost[1] = c->n_export[0] = c->n_export[1] = 0;
     return SPH_OK;
 }

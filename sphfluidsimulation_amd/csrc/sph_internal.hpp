@@ -162,6 +162,7 @@ void launch_density(const Dev &d, hipStream_t s);     // sph_kernels_brick.hip (
 // cur -> nxt; the optional events bracket k_velpos_list (recorded only in a sub-step that uses neighbour lists)
 void launch_velpos(const Dev &d, hipStream_t s, hipEvent_t list_begin = nullptr, hipEvent_t list_end = nullptr);
 void launch_list_prepare(const Dev &d, hipStream_t s);  // sph_kernels_list.hip: which bricks may use their lists
+void launch_frame_report(const Dev &d, unsigned long long *report, bool lists_in_use, hipStream_t s);   // sph_kernels_list.hip
 void launch_velpos_lists(const Dev &d, hipStream_t s, hipEvent_t list_begin = nullptr, hipEvent_t list_end = nullptr);  // sph_kernels_list.hip: the targets of those bricks, cur -> nxt
 
 

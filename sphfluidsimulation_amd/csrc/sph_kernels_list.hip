@@ -344,7 +344,33 @@ __global__ void __launch_bounds__(kBlock, SPH_LIST_MINWAVES) k_velpos_list_chang
     stat_add(d, kStatListEntries, entries);
 }
 
+// End of a frame: how many target sub-steps the lists served so far, into host-visible memory (no synchronisation: the
+// engine's list policy reads it whenever it next issues a frame).  report[0] frames reported, [1] listed target
+// sub-steps (cumulative since the last statistics reset), [2] frames of those that recorded lists.
+__global__ void __launch_bounds__(kStatStripes) k_frame_report(Dev d, unsigned long long *report, int lists_in_use)
+{
+    __shared__ unsigned long long s_part[kStatStripes / kWave];
+    unsigned long long v = d.stripes[((size_t)kStatListed * kStatStripes + threadIdx.x) * kStatPad];
+    v = wave_sum_u64(v);
+    if ((threadIdx.x & (kWave - 1)) == 0) s_part[threadIdx.x / kWave] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long total = 0;
+        for (int w = 0; w < kStatStripes / kWave; w++) total += s_part[w];
+        report[1] = total;
+        report[2] += lists_in_use ? 1ull : 0ull;
+        __threadfence_system();
+        report[0] += 1ull;                         // last: the host takes [1], [2] only as fresh as [0]
+        __threadfence_system();
+    }
+}
+
 static inline uint32_t cdiv(uint32_t a, uint32_t b) { return a ? (a + b - 1) / b : 1u; }
+
+void launch_frame_report(const Dev &d, unsigned long long *report, bool lists_in_use, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_frame_report, dim3(1), dim3(kStatStripes), 0, s, d, report, lists_in_use ? 1 : 0);
+}
 
 void launch_list_prepare(const Dev &d, hipStream_t s)
 {

@@ -47,7 +47,8 @@ class SphFluidSimulation:
         self.device_id = device_id
         self.profile = profile
         self.tiling = tiling            # False: diagnostic per-target kernels (SPH_FLAG_NO_TILING)
-        self.lists = lists              # False: every sub-step re-scans its 27 bins (SPH_FLAG_NO_LISTS)
+        self.lists = lists              # False: every sub-step re-scans its 27 bins (SPH_FLAG_NO_LISTS); "always":
+                                        # record lists every frame instead of only while they pay (SPH_FLAG_LISTS_ALWAYS)
         self.graphs = graphs            # False: no HIP-graph replay of whole frames (SPH_FLAG_NO_GRAPHS)
         self._ctx = C.c_void_p()
         self._derived = None
@@ -65,7 +66,8 @@ class SphFluidSimulation:
         p.damping_coeff = self.dampingCoefficient
         p.device_id = self.device_id
         p.flags = ((N.SPH_FLAG_PROFILE if self.profile else 0) | (0 if self.tiling else N.SPH_FLAG_NO_TILING) |
-                   (0 if self.lists else N.SPH_FLAG_NO_LISTS) | (0 if self.graphs else N.SPH_FLAG_NO_GRAPHS))
+                   (0 if self.lists else N.SPH_FLAG_NO_LISTS) | (0 if self.graphs else N.SPH_FLAG_NO_GRAPHS) |
+                   (N.SPH_FLAG_LISTS_ALWAYS if self.lists == "always" else 0))
         return p
 
     def _check(self, rc):

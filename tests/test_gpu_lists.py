@@ -18,7 +18,7 @@ def _bits(a):
 def _run_pair(n, R, fill, pos0, vel0, frames, dt, **kw):
     from sphfluidsimulation_amd.simulation import SphFluidSimulation
     out = []
-    for lists in (True, False):
+    for lists in ("always", False):     # "always": the policy that drops lists where they do not pay is not under test here
         sim = SphFluidSimulation(particleNumber=n, bucketResolution=R, damFillRate=fill, lists=lists, **kw).Start(pos0, vel0)
         try:
             sim.reset_stats()
@@ -71,7 +71,7 @@ def test_lists_with_reference_dispatch_granularity(oracle):
     pos0, vel0 = presets.dam_break(n, fill, seed=23, jitter=0.3)
     vel0[:, :3] = np.random.default_rng(4).standard_normal((n, 3)).astype(f32) * f32(0.3)
     dt = presets.bench_dt_frame(R) / 25
-    sim = SphFluidSimulation(particleNumber=n, bucketResolution=R, damFillRate=fill).Start(pos0, vel0)
+    sim = SphFluidSimulation(particleNumber=n, bucketResolution=R, damFillRate=fill, lists="always").Start(pos0, vel0)
     osim = oracle.OracleSimulation(oracle.derive(n, R, fill))
     osim.upload(pos0, vel0)
     try:
@@ -123,7 +123,7 @@ def test_lists_blocked_by_out_of_box_upload(oracle):
     pos0[99, 2] = 1.0 + 1e-3
     dt = presets.bench_dt_frame(R)
     from sphfluidsimulation_amd.simulation import SphFluidSimulation
-    sim = SphFluidSimulation(particleNumber=n, bucketResolution=R, damFillRate=fill).Start(pos0, vel0)
+    sim = SphFluidSimulation(particleNumber=n, bucketResolution=R, damFillRate=fill, lists="always").Start(pos0, vel0)
     osim = oracle.OracleSimulation(oracle.derive(n, R, fill))
     osim.upload(pos0, vel0)
     try:
@@ -151,7 +151,7 @@ def test_frame_graph_replay_matches_issued_launches(oracle):
     pos0, vel0 = presets.dam_break(n, fill, seed=41, jitter=0.3)
     base = presets.bench_dt_frame(R) * 0.2
     dts = [base * (1.0 + 0.37 * ((7 * k) % 5)) for k in range(12)]
-    sims = [SphFluidSimulation(particleNumber=n, bucketResolution=R, damFillRate=fill, graphs=g).Start(pos0, vel0)
+    sims = [SphFluidSimulation(particleNumber=n, bucketResolution=R, damFillRate=fill, graphs=g, lists="always").Start(pos0, vel0)
             for g in (True, False)]
     osim = oracle.OracleSimulation(oracle.derive(n, R, fill))
     osim.upload(pos0, vel0)
@@ -190,7 +190,7 @@ def test_one_million_particles_six_frames(oracle):
     n, fill = 1048576, 0.8
     R = presets.scene_bucket_resolution(n)
     dt = presets.bench_dt_frame(R)
-    sim = SphFluidSimulation(preset=0, particleNumber=n, bucketResolution=R, damFillRate=fill).Start(seed=None)
+    sim = SphFluidSimulation(preset=0, particleNumber=n, bucketResolution=R, damFillRate=fill, lists="always").Start(seed=None)
     osim = oracle.OracleSimulation(oracle.derive(n, R, fill))
     osim.upload(oracle.init_particles(0, 1024, fill), np.zeros((n, 4), f32))
     try:
@@ -208,3 +208,35 @@ def test_one_million_particles_six_frames(oracle):
                                                                                sim.particleRadius)))
     finally:
         sim.OnDestroy()
+
+
+def test_list_policy_drops_lists_where_they_do_not_pay(oracle):
+    """Default contexts record neighbour lists only while at least 90 % of the target sub-steps are served from them
+    (SphStats.frames_without_lists).  A 65536-particle box is small: it starts without lists and probes at frame 32;
+    at the full time step it is all wall layer, the probe fails and the back-off doubles; with tiny steps it is calm and
+    the lists stay on.  The results are the oracle's either way, across every switch."""
+    from sphfluidsimulation_amd.simulation import SphFluidSimulation
+    n, fill = 65536, 0.8
+    R = presets.scene_bucket_resolution(n)
+    pos0, vel0 = presets.dam_break(n, fill, seed=43, jitter=0.3)
+    for scale, violent in ((1.0, True), (0.02, False)):
+        dt = presets.bench_dt_frame(R) * scale
+        sim = SphFluidSimulation(particleNumber=n, bucketResolution=R, damFillRate=fill).Start(pos0, vel0)
+        osim = oracle.OracleSimulation(oracle.derive(n, R, fill))
+        osim.upload(pos0, vel0)
+        try:
+            frames = 48
+            for _ in range(frames):
+                sim.Update(dt)
+                sim.synchronize()            # a caller that looks at every frame: the policy sees every report
+                osim.Update(dt)
+            for a, b in zip(sim.download(), osim.download()):
+                assert np.array_equal(_bits(a), _bits(b))
+            st = sim.stats()
+            assert st["listed_target_substeps"] > 0              # the probe ran
+            if violent:
+                assert st["frames_without_lists"] >= 40          # 32 before the probe, and again after it failed
+            else:
+                assert 30 <= st["frames_without_lists"] <= 34    # the probe succeeded: lists from frame 33 on
+        finally:
+            sim.OnDestroy()
