@@ -26,6 +26,14 @@ public class SphHipSimulation : MonoBehaviour
     public Texture2D positionTexture, velocityTexture;   // RGBAFloat, res x res: what the render pass samples
     public bool readBackEveryFrame = true;
 
+    [Header("Rendering (SphFluidSimulation.cs:46-53)")]
+    [Range(0.001f, 1f)] public float particleRadius = 0.01f;
+    [Range(0f, 1000f)] public float lowSpeed = 0f, highSpeed = 0.5f;
+    /// Filled by the library's own UpdateMeshProperties (row f3) instead of positionTexture / velocityTexture:
+    /// 80-byte MeshProperties records, bind it as the material's _Properties (SphFluidSimulation.cs:186).
+    public ComputeBuffer meshPropertiesBuffer;
+    float[] _props;
+
     IntPtr _ctx = IntPtr.Zero;
     SphNative.SphParams _p;
     float[] _pos, _vel;
@@ -73,6 +81,18 @@ public class SphHipSimulation : MonoBehaviour
             _p = p;
         }
         SphNative.Check(SphNative.sph_step(_ctx, Time.deltaTime), _ctx);             // :98-102
+        if (meshPropertiesBuffer != null)                                             // :104, :271-284 on the device
+        {
+            var m = new SphNative.SphMeshParams {
+                struct_size = (uint)System.Runtime.InteropServices.Marshal.SizeOf<SphNative.SphMeshParams>(),
+                low_speed = lowSpeed, high_speed = highSpeed,
+                scale_x = particleRadius, scale_y = particleRadius, scale_z = particleRadius,
+                sim_trs = transform.localToWorldMatrix };
+            SphNative.Check(SphNative.sph_update_mesh_properties(_ctx, ref m), _ctx);
+            if (_props == null) _props = new float[20 * _pos.Length / 4];
+            SphNative.Check(SphNative.sph_download_mesh_properties(_ctx, _props), _ctx);
+            meshPropertiesBuffer.SetData(_props);    // (zero-copy instead: sph_export_mesh_properties_fd + VK_KHR_external_memory_fd)
+        }
         if (readBackEveryFrame && positionTexture != null)
         {
             SphNative.Check(SphNative.sph_download(_ctx, _pos, _vel, null), _ctx);
