@@ -1,16 +1,26 @@
 // Density.compute::CSMain replacement: LDS-tiled brick kernel, see sph_brick_impl.inc.
-// Brick shape and tile size tuned on MI355X at 16.7 M particles (profiles/): 8x4x4 cells, halo 1,
-// 256 threads, 2048-particle tile -> 5 bricks resident per CU.
+// Brick shape and tile size tuned on MI355X at 16.7 M particles (scripts/gpu_variants2.sh): 4x4x4 cells, halo 1,
+// 256 threads, 1024-particle tile -> 7 bricks resident per CU (6 for the instantiation that records neighbour lists:
+// + the slot table).  (8x4x4 cells with a 2048 / 1792-particle tile: 1.71 / 2.37 ms instead of 1.57 / 2.22.)
 #define SPH_BRICK_NS brick_density
+#ifndef SPH_DENSITY_MINWAVES
+#define SPH_DENSITY_MINWAVES 7
+#endif
+#ifndef SPH_RECORD_CAP
+#define SPH_RECORD_CAP 1024
+#endif
+#ifndef SPH_RECORD_MINWAVES
+#define SPH_RECORD_MINWAVES 6
+#endif
 #define SPH_BRICK_EMIT_DENSITY 1
 #ifndef SPH_D_BX
-#define SPH_D_BX 8
+#define SPH_D_BX 4
 #endif
 #ifndef SPH_D_T
 #define SPH_D_T 256
 #endif
 #ifndef SPH_D_CAP
-#define SPH_D_CAP 2048
+#define SPH_D_CAP 1024
 #endif
 #define SPH_BRICK_BX SPH_D_BX
 #define SPH_BRICK_T SPH_D_T
