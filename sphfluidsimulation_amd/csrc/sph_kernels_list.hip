@@ -22,6 +22,10 @@
 namespace sph {
 
 constexpr int kBlock = 256;
+#ifndef SPH_LIST_BLOCK
+#define SPH_LIST_BLOCK 256
+#endif
+constexpr int kListBlock = SPH_LIST_BLOCK;
 #ifndef SPH_LIST_MINWAVES
 #define SPH_LIST_MINWAVES 4
 #endif
@@ -244,11 +248,11 @@ __device__ __forceinline__ void walk_list_and_integrate(const Dev &d, uint32_t s
 // coalesced; the candidates of 64 consecutive slots (~17 bins of one row and their neighbours, ~20 KB of
 // (x,y,z,-) + (rho,vx,vy,vz)) are gathered through L1/L2 -- there is no tile to stage.  The pair arithmetic
 // (~160 VALU instructions per entry, 14 IEEE divisions per two entries) is what bounds the kernel.
-__global__ void __launch_bounds__(kBlock, SPH_LIST_MINWAVES) k_velpos_list(Dev d)
+__global__ void __launch_bounds__(kListBlock, SPH_LIST_MINWAVES) k_velpos_list(Dev d)
 {
     __shared__ uint32_t s_queue[2];
     if (nl_blocked(d)) return;                     // the scanning kernels take everything
-    const uint32_t s_raw = xcd_contiguous_block() * kBlock + threadIdx.x;
+    const uint32_t s_raw = xcd_contiguous_block() * kListBlock + threadIdx.x;
     bool live = s_raw < d.count;
     const uint32_t s = live ? s_raw : 0u;
     ListTarget t = list_target(d, s);
@@ -390,7 +394,7 @@ void launch_velpos_lists(const Dev &d, hipStream_t s, hipEvent_t list_begin, hip
 {
     (void)hipMemsetAsync(d.counters + kCntQueue2, 0, sizeof(unsigned long long), s);
     if (list_begin) (void)hipEventRecord(list_begin, s);     // the events bracket k_velpos_list alone (bench.py roofline)
-    hipLaunchKernelGGL(k_velpos_list, dim3(cdiv(d.count, kBlock)), dim3(kBlock), 0, s, d);
+    hipLaunchKernelGGL(k_velpos_list, dim3(cdiv(d.count, kListBlock)), dim3(kListBlock), 0, s, d);
     if (list_end) (void)hipEventRecord(list_end, s);
     const uint32_t g = cdiv(d.count, kBlock);
     hipLaunchKernelGGL(k_velpos_list_changers, dim3(g < 1024u ? g : 1024u), dim3(kBlock), 0, s, d);
