@@ -307,7 +307,6 @@ __global__ void __launch_bounds__(kBlock, SPH_LIST_MINWAVES) k_velpos_list_chang
         bool live = q < qlen;
         const uint32_t s = d.queue2[live ? q : qlen - 1];
         ListTarget t = list_target(d, s);
-        const int R = (int)d.R;
         bool generic = live && !one_cell_away(t);
         if (live && !generic) {
             // bins of the current stencil that are not in the recorded one: beyond c0 +- 1 on an axis that moved
@@ -342,7 +341,6 @@ __global__ void __launch_bounds__(kBlock, SPH_LIST_MINWAVES) k_velpos_list_chang
         walk_list_and_integrate(d, s, n, shifted_mask(t), live, t.px, t.py, t.pz);
         served += live ? 1ull : 0ull;
         entries += n;
-        (void)R;
     }
     stat_add(d, kStatListed, served);
     stat_add(d, kStatListEntries, entries);
