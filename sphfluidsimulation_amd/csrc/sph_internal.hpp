@@ -157,6 +157,7 @@ void launch_upload_split(const Dev &d, const float4 *pos4, const float4 *vel4, f
 void launch_download_merge(const Dev &d, const float *pw0, int substeps_done, float dt_last,
                            float4 *pos4, float4 *vel4, float *rho_by_id, hipStream_t s);
 void launch_set_scalar(float *p, float v, hipStream_t s);
+void launch_clear(const Dev &d, uint32_t counter_mask, uint32_t stat_mask, hipStream_t s);   // counters / striped statistics
 void launch_grid_build(const Dev &d, hipStream_t s);  // keys, histogram, scan, scatter, id-sort, reorder: cur -> nxt
 void launch_density(const Dev &d, hipStream_t s);     // sph_kernels_brick.hip (tiled) + queue
 // cur -> nxt; the optional events bracket k_velpos_list (recorded only in a sub-step that uses neighbour lists)

@@ -271,12 +271,30 @@ __global__ void __launch_bounds__(kBlock) k_reorder(Dev d)
     }
 }
 
+// Zeroes the device counters named by `counter_mask` (bit = Counter) and the striped statistics named by `stat_mask`
+// (bit = Stat) in ONE launch: a pass used to start with up to four 8-byte memsets, ~5 us each on the stream -- a tenth of
+// a frame of the reference's own 262 144-particle scene.
+__global__ void __launch_bounds__(kStatStripes) k_clear(Dev d, uint32_t counter_mask, uint32_t stat_mask)
+{
+    const uint32_t t = threadIdx.x;
+    if (t < (uint32_t)kCntCount && ((counter_mask >> t) & 1u)) d.counters[t] = 0ull;
+#pragma unroll
+    for (int k = 0; k < kStatCount; k++)
+        if ((stat_mask >> k) & 1u) d.stripes[((size_t)k * kStatStripes + t) * kStatPad] = 0ull;
+}
+
 // one float into device memory, the value travelling in the launch packet (no host staging buffer to race with)
 __global__ void k_set_scalar(float *p, float v) { *p = v; }
 
 // ---- launchers ---------------------------------------------------------------------------------
 
 void launch_set_scalar(float *p, float v, hipStream_t s) { hipLaunchKernelGGL(k_set_scalar, dim3(1), dim3(1), 0, s, p, v); }
+
+void launch_clear(const Dev &d, uint32_t counter_mask, uint32_t stat_mask, hipStream_t s)
+{
+    static_assert(kCntCount <= 32 && kStatCount <= 32 && kCntCount <= kStatStripes, "one bit, one thread per counter");
+    hipLaunchKernelGGL(k_clear, dim3(1), dim3(kStatStripes), 0, s, d, counter_mask, stat_mask);
+}
 
 static inline uint32_t cdiv(uint32_t a, uint32_t b) { return a ? (a + b - 1) / b : 1u; }  // never an empty grid
 
@@ -300,8 +318,7 @@ void launch_grid_build(const Dev &d, hipStream_t s)
     // order_tmp lives behind order (allocated 2*count)
     uint2 *order_tmp = d.order + d.count;
     (void)hipMemsetAsync(d.cell_count, 0, sizeof(uint32_t) * (size_t)n, s);
-    (void)hipMemsetAsync(d.counters + kCntMaxOcc, 0, sizeof(unsigned long long) * 3, s);
-    (void)hipMemsetAsync(d.counters + kCntIrregular, 0, sizeof(unsigned long long), s);
+    launch_clear(d, 1u << kCntMaxOcc | 1u << kCntOverflowCells | 1u << kCntDropped | 1u << kCntIrregular, 0u, s);
     hipLaunchKernelGGL(k_cell_key_hist, dim3(pb), dim3(kBlock), 0, s, d);
     hipLaunchKernelGGL(k_scan_reduce, dim3(nb), dim3(kScanThreads), 0, s, d, n);
     hipLaunchKernelGGL(k_scan_blocksums, dim3(1), dim3(kScanThreads), 0, s, d, nb);

@@ -377,7 +377,6 @@ void launch_frame_report(const Dev &d, unsigned long long *report, bool lists_in
 void launch_list_prepare(const Dev &d, hipStream_t s)
 {
     const uint32_t nbx = nl_bricks_x(d.R), nby = nl_bricks_y(d.R), nbz = nl_bricks_z(d.R);
-    (void)hipMemsetAsync(d.counters + kCntActiveCount, 0, sizeof(unsigned long long), s);
     if (!d.nl_still) hipLaunchKernelGGL(k_chunk_box, dim3(cdiv(d.count, kBlock)), dim3(kBlock), 0, s, d);
     // the brick layers along z with planes that hold targets (z-slab mode: this rank's planes)
     const int zl = d.zo_lo < 0 ? 0 : d.zo_lo, zh = d.zo_hi > (int)d.R ? (int)d.R : d.zo_hi;
@@ -390,7 +389,6 @@ void launch_list_prepare(const Dev &d, hipStream_t s)
 
 void launch_velpos_lists(const Dev &d, hipStream_t s, hipEvent_t list_begin, hipEvent_t list_end)
 {
-    (void)hipMemsetAsync(d.counters + kCntQueue2, 0, sizeof(unsigned long long), s);
     if (list_begin) (void)hipEventRecord(list_begin, s);     // the events bracket k_velpos_list alone (bench.py roofline)
     hipLaunchKernelGGL(k_velpos_list, dim3(cdiv(d.count, kListBlock)), dim3(kListBlock), 0, s, d);
     if (list_end) (void)hipEventRecord(list_end, s);
