@@ -392,6 +392,7 @@ void launch_velpos_lists(const Dev &d, hipStream_t s, hipEvent_t list_begin, hip
     if (list_begin) (void)hipEventRecord(list_begin, s);     // the events bracket k_velpos_list alone (bench.py roofline)
     hipLaunchKernelGGL(k_velpos_list, dim3(cdiv(d.count, kListBlock)), dim3(kListBlock), 0, s, d);
     if (list_end) (void)hipEventRecord(list_end, s);
+    if (d.nl_still) return;                        // first sub-step: nobody has changed cell, nothing was handed over
     const uint32_t g = cdiv(d.count, kBlock);
     hipLaunchKernelGGL(k_velpos_list_changers, dim3(g < 1024u ? g : 1024u), dim3(kBlock), 0, s, d);
 }
