@@ -311,7 +311,7 @@ static void ensure_lists(SphContext *c)
     const bool ok = dalloc(c, &d.p1x, n) == SPH_OK && dalloc(c, &d.p1y, n) == SPH_OK && dalloc(c, &d.p1z, n) == SPH_OK &&
                     dalloc(c, &d.nl_ent, (size_t)d.nl_cap * ((n + 63) & ~(size_t)63)) == SPH_OK && dalloc(c, &d.nl_cnt, n) == SPH_OK &&
                     dalloc(c, &d.chunk_box, 6 * ((n + 63) / 64)) == SPH_OK &&
-                    dalloc(c, &d.brick_rho, 3 * bricks) == SPH_OK && dalloc(c, &d.active_list, bricks) == SPH_OK && dalloc(c, &d.queue2, n) == SPH_OK && dalloc(c, &d.brick_state, bricks) == SPH_OK &&
+                    dalloc(c, &d.active_list, bricks) == SPH_OK && dalloc(c, &d.queue2, n) == SPH_OK && dalloc(c, &d.brick_state, bricks) == SPH_OK &&
                     dalloc(c, &d.cur.p4, n) == SPH_OK && dalloc(c, &d.nxt.p4, n) == SPH_OK;
     if (!ok) {
         while (c->allocs.size() > before) {
@@ -322,7 +322,7 @@ static void ensure_lists(SphContext *c)
         d.p1x = d.p1y = d.p1z = nullptr;
         d.nl_ent = nullptr;
         d.nl_cnt = nullptr;
-        d.chunk_box = d.brick_rho = nullptr;
+        d.chunk_box = nullptr;
         d.active_list = nullptr;
         d.queue2 = nullptr;
         d.brick_state = nullptr;

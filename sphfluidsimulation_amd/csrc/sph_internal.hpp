@@ -70,7 +70,6 @@ struct Dev {
     uint32_t *queue2;      // [count]: targets that changed cell and may see a bin that entered their stencil
     uint32_t *active_list; // [bricks]: the bricks the scanning kernel must take this sub-step (kNlUse)
     uint8_t *brick_state;  // [bricks]: kBrickUnlisted (set while building), kBrickActive (set per sub-step)
-    float *brick_rho;      // [3][bricks]: per-axis bound on |delta_i - delta_j| around the brick, this sub-step
     float h2_list;         // pre-filter radius^2 of the building sub-step: (h + skin)^2, rounded up
     float skin_ok;         // a brick is calm while the relative displacement bound stays <= this
 };

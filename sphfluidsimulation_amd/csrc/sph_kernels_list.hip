@@ -10,10 +10,11 @@
 //       (k_chunk_box: per-axis displacement range of every 64 consecutive slots; k_brick_activity: merged over the
 //       slot runs that cover the brick's bins and their neighbours);
 //   (2) the target's stencil is still known: its current cell is its bin or a face/edge/corner neighbour.  Bins that
-//       left the stencil are masked per entry (the reference no longer visits them); a bin that entered it lies beyond
-//       a face the target crossed since, along that axis at least one cell + a from where the target was when the
-//       lists were built (a = its distance to that face then), so it holds nothing within h = one cell while a is at
-//       least the range of the displacements along that axis (two cells around the brick).
+//       left the stencil are masked per entry (the reference no longer visits them).  A bin that ENTERED it was not
+//       scanned when the lists were recorded: k_velpos_list_changers runs the distance pre-test over the listed
+//       particles of those <= 19 bins for every target that changed cell (~1 % per sub-step) and, if one is within h --
+//       practically never: it was more than a cell away then -- queues the target for the generic scan, whose result
+//       replaces the one k_velpos_list wrote (both read the same inputs).
 // Everything else -- bricks that are not calm, targets failing (2), bricks with an unlistable target -- takes the
 // scanning kernels exactly as without lists.  Out-of-range entries contribute exact zeros (VelPos.compute:37,43 and
 // the "wild" guard of sph_kernels_sweep.hip), so which path served a target does not change a bit of the result.
@@ -121,7 +122,6 @@ __global__ void __launch_bounds__(kBlock) k_brick_activity(Dev d, int nbx, int n
         for (int a = 0; a < 3; a++) {
             r[a] = (hi[a] >= lo[a] ? hi[a] - lo[a] : 0.0f) * 1.00001f;   // empty neighbourhood: nothing moved
             r2 += r[a] * r[a];
-            d.brick_rho[(size_t)a * d.n_bricks + b] = r[a];              // per axis: what condition (2) compares with
         }
         const float rho = sqrtf(r2) * 1.00001f;
         const uint8_t st = d.brick_state[b] & kBrickUnlisted;
@@ -264,26 +264,12 @@ __global__ void __launch_bounds__(kListBlock, SPH_LIST_MINWAVES) k_velpos_list(D
     live = live && !(d.brick_state[brick] & kBrickActive);                       // else the scanning kernel takes it
     bool hand_over = false;
     if (live && (t.shx | t.shy | t.shz) != 0) {
-        // condition (2): at most one cell away, and -- along every axis it crossed a face of -- deeper behind that face
-        // when the lists were built than any two particles around the brick have moved apart along that axis since
-        // (cell units; the constants absorb the fp32 rounding of u and of the ranges)
-        const float nx = d.brick_rho[brick] * d.Rm1 * 1.0001f + 1e-4f,
-                    ny = d.brick_rho[(size_t)d.n_bricks + brick] * d.Rm1 * 1.0001f + 1e-4f,
-                    nz = d.brick_rho[2 * (size_t)d.n_bricks + brick] * d.Rm1 * 1.0001f + 1e-4f;
-        const float ux = t.qx * d.Rm1, uy = t.qy * d.Rm1, uz = t.qz * d.Rm1;
-        bool ok = one_cell_away(t);
-        if (t.shx > 0) ok = ok && ((float)(t.c0x + 1) - ux >= nx);
-        if (t.shx < 0) ok = ok && (ux - (float)t.c0x >= nx);
-        if (t.shy > 0) ok = ok && ((float)(t.c0y + 1) - uy >= ny);
-        if (t.shy < 0) ok = ok && (uy - (float)t.c0y >= ny);
-        if (t.shz > 0) ok = ok && ((float)(t.c0z + 1) - uz >= nz);
-        if (t.shz < 0) ok = ok && (uz - (float)t.c0z >= nz);
-        if (!ok) {
-            hand_over = true;                      // k_velpos_list_changers looks into the bins that entered the stencil
-            live = false;
-        } else {
-            t.mask = shifted_mask(t);
-        }
+        // condition (2): the target changed cell.  One cell away, its recorded list minus the bins that left the stencil
+        // is complete unless a bin that ENTERED the stencil holds something within h -- k_velpos_list_changers looks, and
+        // in the (rare) positive case has the generic kernel redo the target.  Further away: generic kernel at once.
+        hand_over = true;
+        if (one_cell_away(t)) t.mask = shifted_mask(t);
+        else live = false;
     }
     if (live && (t.c0z + t.shz < d.zt_lo || t.c0z + t.shz > d.zt_hi)) atomicAdd(&d.counters[kCntHaloViolation], 1ull);
     enqueue_block(d, hand_over, s, s_queue, d.queue2, kCntQueue2);
@@ -293,20 +279,18 @@ __global__ void __launch_bounds__(kListBlock, SPH_LIST_MINWAVES) k_velpos_list(D
     stat_add(d, kStatListEntries, (unsigned long long)n);
 }
 
-// The targets k_velpos_list handed over: they sit in a cell next to their bin and close behind the face they crossed,
-// so a bin that ENTERED their stencil might hold a candidate within h.  One lane per such target looks (distance
-// pre-test on the listed particles of those <= 19 bins): almost never -- then the recorded list, minus the bins that
-// left the stencil, is complete and the target is integrated here; otherwise, and when it is more than one cell away,
-// the generic scanning kernel takes it.
-__global__ void __launch_bounds__(kBlock, SPH_LIST_MINWAVES) k_velpos_list_changers(Dev d)
+// The targets of k_velpos_list that changed cell since the lists were recorded: a bin that ENTERED their stencil might
+// hold a candidate within h.  One lane per such target looks (distance pre-test on the listed particles of those <= 19
+// bins); if it finds one, or if the target is more than one cell from its bin (k_velpos_list did not integrate it), the
+// generic scanning kernel takes the target -- and overwrites what k_velpos_list stored for it.
+__global__ void __launch_bounds__(kBlock) k_velpos_list_changers(Dev d)
 {
     const uint32_t qlen = (uint32_t)d.counters[kCntQueue2];
-    unsigned long long served = 0, entries = 0;
     for (uint32_t q0 = blockIdx.x * kBlock; q0 < qlen; q0 += gridDim.x * kBlock) {   // block-uniform
         const uint32_t q = q0 + threadIdx.x;
-        bool live = q < qlen;
+        const bool live = q < qlen;
         const uint32_t s = d.queue2[live ? q : qlen - 1];
-        ListTarget t = list_target(d, s);
+        const ListTarget t = list_target(d, s);
         bool generic = live && !one_cell_away(t);
         if (live && !generic) {
             // bins of the current stencil that are not in the recorded one: beyond c0 +- 1 on an axis that moved
@@ -324,26 +308,15 @@ __global__ void __launch_bounds__(kBlock, SPH_LIST_MINWAVES) k_velpos_list_chang
                 }
             }
         }
-        // (wave-aggregated: this is rare)
-        {
-            const unsigned long long m = __ballot(generic);
-            if (m) {
-                const int lane = threadIdx.x & (kWave - 1), leader = __ffsll((long long)m) - 1;
-                unsigned long long base = 0;
-                if (lane == leader) base = atomicAdd(&d.counters[kCntQueue], (unsigned long long)__popcll(m));
-                base = __shfl(base, leader, kWave);
-                if (generic) d.queue[base + (unsigned long long)__popcll(m & ((1ull << lane) - 1ull))] = s;
-            }
+        const unsigned long long m = __ballot(generic);                          // (wave-aggregated: this is rare)
+        if (m) {
+            const int lane = threadIdx.x & (kWave - 1), leader = __ffsll((long long)m) - 1;
+            unsigned long long base = 0;
+            if (lane == leader) base = atomicAdd(&d.counters[kCntQueue], (unsigned long long)__popcll(m));
+            base = __shfl(base, leader, kWave);
+            if (generic) d.queue[base + (unsigned long long)__popcll(m & ((1ull << lane) - 1ull))] = s;
         }
-        live = live && !generic;
-        if (live && (t.c0z + t.shz < d.zt_lo || t.c0z + t.shz > d.zt_hi)) atomicAdd(&d.counters[kCntHaloViolation], 1ull);
-        const uint32_t n = live ? d.nl_cnt[s] : 0u;
-        walk_list_and_integrate(d, s, n, shifted_mask(t), live, t.px, t.py, t.pz);
-        served += live ? 1ull : 0ull;
-        entries += n;
     }
-    stat_add(d, kStatListed, served);
-    stat_add(d, kStatListEntries, entries);
 }
 
 // End of a frame: how many target sub-steps the lists served so far, into host-visible memory (no synchronisation: the
