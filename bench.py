@@ -141,6 +141,14 @@ def main():
     elapsed = time.perf_counter() - t0
 
     st = sim.stats()
+    # SURVEY.md 8d asks for median and mean: a few more frames, each synchronised and timed on its own (never part of `value`)
+    singles = []
+    for _ in range(min(a.steps, 10)):
+        sim.synchronize()
+        ts = time.perf_counter()
+        sim.Update(dt_frame)
+        sim.synchronize()
+        singles.append((time.perf_counter() - ts) * 1e3)
     # row f3, the render feed after the path (UpdateMeshProperties, never part of `value`): 112 B per particle
     sim.UpdateMeshProperties()
     sim.synchronize()
@@ -184,6 +192,8 @@ def main():
                       "density": st["ms_density"] / max(st["launches_density"], 1),
                       "velpos": vel_ms},
         "particle_substeps_per_s": value * 5,
+        "single_frames_ms": {"n": len(singles), "median": float(np.median(singles)) if singles else None,
+                             "mean": float(np.mean(singles)) if singles else None},
         "host_boundary": {"upload_ms": (t2 - t1) * 1e3, "download_ms": (t3 - t2) * 1e3,
                           "pcie_inclusive_particle_steps_per_s": n / (elapsed / a.steps + (t3 - t1))},
         "render_feed": {"kernel": "k_mesh_properties", "ms": mesh_ms, "algorithmic_bytes": 112 * n,
