@@ -8,7 +8,7 @@
 //   (1) no unlisted candidate of those bins can have come within h: its distance was >= h + skin and the relative
 //       displacement |delta_i - delta_j| of any pair around the target's brick is bounded by rho <= skin
 //       (k_chunk_box: per-axis displacement range of every 64 consecutive slots; k_brick_activity: merged over the
-//       slot runs that cover the brick's bins and their neighbours);
+//       slot runs that cover the brick's bins and their neighbours: one cell around the brick);
 //   (2) the target's stencil is still known: its current cell is its bin or a face/edge/corner neighbour.  Bins that
 //       left the stencil are masked per entry (the reference no longer visits them).  A bin that ENTERED it was not
 //       scanned when the lists were recorded: k_velpos_list_changers runs the distance pre-test over the listed
@@ -68,10 +68,9 @@ __global__ void __launch_bounds__(kBlock) k_chunk_box(Dev d)
     }
 }
 
-// One wave per brick (4 bricks per block), one lane per (y,z) row of the bins within TWO cells of the brick's bins
-// (8 x 8 rows; a row of bins is one run of slots): the per-axis ranges of the displacement over the 64-slot chunks those
-// runs touch bound |delta_i - delta_j| for a target i of the brick and any j in its recorded stencil (one cell away,
-// condition 1) or in a bin that may enter its stencil (two cells away, condition 2).
+// One wave per brick (4 bricks per block), one lane per (y,z) row of the brick's bins and their neighbours (6 x 6 rows; a
+// row of bins is one run of slots): the per-axis ranges of the displacement over the 64-slot chunks those runs touch bound
+// |delta_i - delta_j| for a target i of the brick and any j in its recorded stencil (condition 1).
 // calm <=> every target of the brick has its list and the Euclidean bound rho <= skin_ok.
 __global__ void __launch_bounds__(kBlock) k_brick_activity(Dev d, int nbx, int nby, int first, int n_bricks)
 {
@@ -83,7 +82,7 @@ __global__ void __launch_bounds__(kBlock) k_brick_activity(Dev d, int nbx, int n
     if (threadIdx.x == 0) s_act[0] = 0;
     __syncthreads();
     const int x0 = (b % nbx) * kNlBX, y0 = ((b / nbx) % nby) * kNlBY, z0 = (b / (nbx * nby)) * kNlBZ;
-    constexpr int kRY = kNlBY + 4, kRZ = kNlBZ + 4;
+    constexpr int kRY = kNlBY + 2, kRZ = kNlBZ + 2;
     static_assert(kRY * kRZ <= kWave, "one lane per row");
     float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
     bool own_nonempty = false;
@@ -91,9 +90,9 @@ __global__ void __launch_bounds__(kBlock) k_brick_activity(Dev d, int nbx, int n
         lo[0] = lo[1] = lo[2] = hi[0] = hi[1] = hi[2] = 0.0f;
         own_nonempty = true;
     } else if (lane < kRY * kRZ) {
-        const int cy = y0 - 2 + lane % kRY, cz = z0 - 2 + lane / kRY;
+        const int cy = y0 - 1 + lane % kRY, cz = z0 - 1 + lane / kRY;
         if (cy >= 0 && cz >= 0 && cy < R && cz < R) {
-            const int xa = x0 - 2 > 0 ? x0 - 2 : 0, xb = x0 + kNlBX + 1 < R - 1 ? x0 + kNlBX + 1 : R - 1;   // bins xa..xb
+            const int xa = x0 - 1 > 0 ? x0 - 1 : 0, xb = x0 + kNlBX < R - 1 ? x0 + kNlBX : R - 1;   // bins xa..xb
             const uint32_t rk = (uint32_t)cy * d.R + (uint32_t)cz * d.R * d.R;
             const uint32_t s0 = d.cell_start[rk + (uint32_t)xa], s1 = d.cell_start[rk + (uint32_t)xb + 1u];
             if (s1 > s0) {
