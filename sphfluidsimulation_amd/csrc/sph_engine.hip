@@ -306,11 +306,11 @@ static void ensure_lists(SphContext *c)
     const size_t bricks = (size_t)nl_bricks_x(d.R) * nl_bricks_y(d.R) * nl_bricks_z(d.R);
     d.nl_cap = 64;
     d.n_bricks = (uint32_t)bricks;
-    d.n_chunks = (uint32_t)((n + 63) / 64);
+    d.n_chunks = (uint32_t)((n + kChunkSlots - 1) / kChunkSlots);
     const size_t before = c->allocs.size();
     const bool ok = dalloc(c, &d.p1x, n) == SPH_OK && dalloc(c, &d.p1y, n) == SPH_OK && dalloc(c, &d.p1z, n) == SPH_OK &&
                     dalloc(c, &d.nl_ent, (size_t)d.nl_cap * ((n + 63) & ~(size_t)63)) == SPH_OK && dalloc(c, &d.nl_cnt, n) == SPH_OK &&
-                    dalloc(c, &d.chunk_box, 6 * ((n + 63) / 64)) == SPH_OK &&
+                    dalloc(c, &d.chunk_box, 6 * ((n + kChunkSlots - 1) / kChunkSlots)) == SPH_OK &&
                     dalloc(c, &d.active_list, bricks) == SPH_OK && dalloc(c, &d.queue2, n) == SPH_OK && dalloc(c, &d.brick_state, bricks) == SPH_OK &&
                     dalloc(c, &d.cur.p4, n) == SPH_OK && dalloc(c, &d.nxt.p4, n) == SPH_OK;
     if (!ok) {

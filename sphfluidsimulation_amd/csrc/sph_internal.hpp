@@ -65,7 +65,7 @@ struct Dev {
                            //   order; the lists of 64 consecutive slots interleaved: a wave reads one 256 B row per entry
     uint16_t *nl_cnt;      // by slot: entries recorded
     uint32_t nl_cap;
-    float *chunk_box;      // [6][chunks]: min x,y,z / max x,y,z of the displacement (cur - p1) over each 64 consecutive slots
+    float *chunk_box;      // [6][chunks]: min x,y,z / max x,y,z of the displacement (cur - p1) over each kChunkSlots consecutive slots
     uint32_t n_chunks, n_bricks;
     uint32_t *queue2;      // [count]: targets that changed cell and may see a bin that entered their stencil
     uint32_t *active_list; // [bricks]: the bricks the scanning kernel must take this sub-step (kNlUse)
@@ -76,6 +76,10 @@ struct Dev {
 
 enum : uint32_t { kNlOff = 0, kNlBuild = 1, kNlUse = 2 };
 enum : uint8_t { kBrickUnlisted = 1, kBrickActive = 2 };
+#ifndef SPH_CHUNK_SLOTS
+#define SPH_CHUNK_SLOTS 64
+#endif
+constexpr int kChunkSlots = SPH_CHUNK_SLOTS;      // consecutive slots per displacement box (a power of two <= 64)
 constexpr uint32_t kNlSlotBits = 27;             // entry = cell code << 27 | slot
 constexpr int kNlBX = 4, kNlBY = 4, kNlBZ = 4;   // brick shape of the VelPos kernels (sph_kernels_brick_velpos.hip)
 

@@ -54,12 +54,12 @@ __global__ void __launch_bounds__(kBlock) k_chunk_box(Dev d)
 #pragma unroll
     for (int a = 0; a < 3; a++)
 #pragma unroll
-        for (int o = kWave / 2; o > 0; o >>= 1) {
+        for (int o = kChunkSlots / 2; o > 0; o >>= 1) {
             lo[a] = fminf(lo[a], __shfl_xor(lo[a], o, kWave));
             hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], o, kWave));
         }
-    const uint32_t chunk = s / kWave;
-    if ((threadIdx.x & (kWave - 1)) == 0 && chunk < d.n_chunks) {
+    const uint32_t chunk = s / kChunkSlots;
+    if ((threadIdx.x & (kChunkSlots - 1)) == 0 && chunk < d.n_chunks) {
 #pragma unroll
         for (int a = 0; a < 3; a++) {
             d.chunk_box[(size_t)a * d.n_chunks + chunk] = lo[a];
@@ -97,7 +97,7 @@ __global__ void __launch_bounds__(kBlock) k_brick_activity(Dev d, int nbx, int n
             const uint32_t s0 = d.cell_start[rk + (uint32_t)xa], s1 = d.cell_start[rk + (uint32_t)xb + 1u];
             if (s1 > s0) {
                 own_nonempty = cy >= y0 && cy < y0 + kNlBY && cz >= z0 && cz < z0 + kNlBZ;   // (roughly: the row)
-                for (uint32_t c = s0 / kWave; c <= (s1 - 1) / kWave; c++)
+                for (uint32_t c = s0 / kChunkSlots; c <= (s1 - 1) / kChunkSlots; c++)
 #pragma unroll
                     for (int a = 0; a < 3; a++) {
                         lo[a] = fminf(lo[a], d.chunk_box[(size_t)a * d.n_chunks + c]);
