@@ -267,3 +267,38 @@ def test_scene_size_120_frames_default_context(oracle):
         assert st["graph_replays"] >= 100 and st["listed_target_substeps"] > 0 and st["frames_without_lists"] > 60
     finally:
         sim.OnDestroy()
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("SPH_FUZZ_SEEDS", "10"))))
+def test_random_configurations_all_paths(oracle, seed):
+    """Random sizes, grids, fill rates, speeds, time steps, inspector scalars and list modes: whatever mixture of list,
+    scanning, hand-over, generic, graph-replay and policy paths a configuration ends up on, the state after a few
+    frames is the oracle's."""
+    from sphfluidsimulation_amd.simulation import SphFluidSimulation
+    rng = np.random.default_rng(1000 + seed)
+    n = int(rng.choice([1024, 4096, 16384, 65536]))
+    R = int(rng.integers(4, 40)) if seed % 3 else int(rng.choice([2, 3, 64, 128, 256]))
+    fill = float(rng.choice([0.3, 0.5, 0.8, 1.0]))
+    speed = float(rng.choice([0.0, 0.05, 0.5, 5.0]))
+    lists = [True, "always", False][seed % 3]
+    scal = dict(viscosity=float(rng.uniform(0.0, 0.1)), restDensity=float(rng.uniform(0.5, 3.0)),
+                gasConstant=float(rng.uniform(10.0, 500.0)), stiffnessCoefficient=float(rng.uniform(1000.0, 10000.0)),
+                dampingCoefficient=float(rng.uniform(1.0, 50.0)))
+    pos0, vel0 = presets.dam_break(n, fill, seed=seed, jitter=float(rng.choice([0.0, 0.3, 1.0])))
+    vel0[:, :3] = rng.standard_normal((n, 3)).astype(f32) * f32(speed)
+    dt = float(rng.uniform(0.05, 1.0)) / (R - 1 if R > 1 else 1) * 0.7666667
+    frames = int(rng.integers(3, 9))
+    sim = SphFluidSimulation(particleNumber=n, bucketResolution=R, damFillRate=fill, lists=lists, **scal).Start(pos0, vel0)
+    osim = oracle.OracleSimulation(oracle.derive(n, R, fill, viscosity=scal["viscosity"], rest_density=scal["restDensity"],
+                                                 gas_constant=scal["gasConstant"], stiffness=scal["stiffnessCoefficient"],
+                                                 damping=scal["dampingCoefficient"]))
+    osim.upload(pos0, vel0)
+    try:
+        for _ in range(frames):
+            sim.Update(dt)
+            osim.Update(dt)
+        for a, b, name in zip(sim.download(), osim.download(), ("pos", "vel", "rho")):
+            same = (_bits(a) == _bits(b)) | (np.isnan(a) & np.isnan(b))
+            assert same.all(), f"{name}: n={n} R={R} fill={fill} speed={speed} lists={lists} frames={frames}"
+    finally:
+        sim.OnDestroy()
