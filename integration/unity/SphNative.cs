@@ -6,6 +6,8 @@ using System;
 using System.Runtime.InteropServices;
 using UnityEngine;   // Matrix4x4 in SphMeshParams
 
+// (Not bound here: sph_set_stream and the sph_slab_* entry points -- the z-slab mode is driven by one process per GPU with
+// a halo exchange between them, sphfluidsimulation_amd/distributed.py; a single Unity process has no use for it.)
 public static class SphNative
 {
     const string Lib = "sph_hip";
