@@ -1,7 +1,11 @@
 #!/usr/bin/env python3
 """Headline benchmark: particle-steps/s of the SPH frame update on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W        (N=1 default; N>1 via torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
+
+N = 1 (default): one GPU.  N > 1: one rank per GPU -- either launched by torch.distributed.run (RANK / LOCAL_RANK /
+WORLD_SIZE in the environment) or, when started plainly, bench.py starts its own N rank processes BEFORE anything touches
+a GPU and relays rank 0's line.
 
 One "step" = one reference frame, SphFluidSimulation.cs::Update (:96-102): grid build + density
 pass + 5 force/integrate sub-steps, on the synthetic dam-break of BASELINE.json
@@ -13,15 +17,20 @@ Extra objects on that line:
                 lists; k_velpos_brick when lists are off): algorithmic bytes per launch
                 (52 B/particle) / its mean launch duration from HIP events recorded
                 around that kernel on the engine's stream inside the timed region, against the
-                8 TB/s HBM peak.  The sweeps are FP32-VALU bound: valu_frac is next to it.
-  cpu_baseline  oracle/ (CPU restatement of the reference, "port") timed on this host for ONE frame
-                of the same workload, all OpenMP threads; also used to check the GPU result.
+                8 TB/s HBM peak.  The sweeps are FP32-VALU bound: `valu_issue_frac` is the kernel's
+                EXECUTED vector instructions per second (SQ_INSTS_VALU of the committed rocprofv3 --pmc run of this
+                command, profiles/*_sq_pmc.csv) against the chip's issue peak (1024 SIMDs x 2.4 GHz / 2 cycles), and
+                `bound` names the larger of the two fractions.
+  cpu_baseline  oracle/ (CPU restatement of the reference, "port") timed on this host: 3 frames of the same workload on
+                all OpenMP threads (also the parity check of the GPU result), plus the reference's own scene size
+                (262 144, all threads and 1 thread) and the 4 096-particle case.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -32,8 +41,8 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 VALU_PEAK_TFLOPS = 157.3       # fp32 vector peak
+VALU_ISSUE_PEAK = 1024 * 2.4e9 / 2.0   # wave64 vector instructions per second: 256 CUs x 4 SIMDs, 2 cycles each at 2.4 GHz
 BYTES_PER_SUBSTEP = 52         # (12 pos + 12 vel + 4 rho) R + (12 + 12) W
-BYTES_PER_STEP = 32 + 52 * 5   # 292 B per particle-step at S = 5
 FLOPS_DENSITY, FLOPS_FORCE = 16, 55  # per candidate, SURVEY.md 8d
 
 
@@ -45,60 +54,110 @@ def parse():
     ap.add_argument("--particles", type=int, default=16777216)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the S = 1 variant and the late-phase (frames 281-300) figure")
     ap.add_argument("--force-slab", action="store_true", help="diagnostic: run the z-slab driver even with one rank")
     return ap.parse_args()
 
 
-CPU_FRAMES = 2   # frame 1 scans (the jittered lattice starts partly outside the unit box), frame 2 walks neighbour lists
+CPU_FRAMES = 3   # frame 1 scans (the jittered lattice starts partly outside the unit box), frames 2-3 walk neighbour lists
 
 
-def cpu_baseline(n, R, fill, pos0, vel0, dt_frame):
-    """Oracle timed on the host cores for CPU_FRAMES frames of the same workload (checker + baseline)."""
-    from oracle import sph_oracle as O
-    O.build()
-    threads = O.max_threads()
+def oracle_run(O, n, R, fill, pos0, vel0, dt_frame, frames, threads):
     p = O.derive(n, R, fill, viscosity=0.01, rest_density=1.5, gas_constant=150.0, stiffness=5000.0,
                  damping=10.0, num_threads=threads)
     sim = O.OracleSimulation(p)
     sim.upload(pos0, vel0)
     t0 = time.perf_counter()
-    for _ in range(CPU_FRAMES):
+    for _ in range(frames):
         sim.Update(dt_frame)
     dt = time.perf_counter() - t0
     out = sim.download()
     sim.close()
-    return dict(value=n * CPU_FRAMES / dt, unit="particle-steps/s", cores=threads, kind="port",
+    return n * frames / dt, dt, out
+
+
+def cpu_baseline(n, R, fill, pos0, vel0, dt_frame):
+    """Oracle timed on the host cores (checker + baseline): CPU_FRAMES frames of the bench workload on all threads, and
+    the smaller configurations SURVEY.md 8d lists."""
+    from oracle import sph_oracle as O
+    from sphfluidsimulation_amd import presets
+    O.build()
+    threads = O.max_threads()
+    rate, dt, out = oracle_run(O, n, R, fill, pos0, vel0, dt_frame, CPU_FRAMES, threads)
+    base = dict(value=rate, unit="particle-steps/s", cores=threads, kind="port",
                 sample=f"{CPU_FRAMES} frames (grid + density + 5 sub-steps each) of the same {n}-particle dam-break, "
-                       f"{dt:.2f} s wall, OpenMP {threads} threads, gcc -O2 -ffp-contract=off"), out
+                       f"{dt:.2f} s wall, OpenMP {threads} threads, gcc -O2 -ffp-contract=off")
+    other = {}
+    for name, nn, frames, thr in (("C0_4096_all_threads", 4096, 20, threads), ("C1_262144_all_threads", 262144, 5, threads),
+                                  ("C1_262144_1_thread", 262144, 1, 1)):
+        RR = presets.scene_bucket_resolution(nn)
+        p0, v0 = presets.dam_break(nn, fill, 1)
+        r, d, _ = oracle_run(O, nn, RR, fill, p0, v0, presets.bench_dt_frame(RR), frames, thr)
+        other[name] = {"value": r, "unit": "particle-steps/s", "cores": thr, "frames": frames, "wall_s": d}
+    base["other_configs"] = other
+    return base, out
 
 
-def pmc_traffic(kernel_substr):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC run
-    (profiles/*_hbm_traffic_pmc.csv: FETCH_SIZE and WRITE_SIZE in separate passes, KiB).  FETCH_SIZE is
-    doubled as MI355X_MICROARCH.md prescribes for wide streaming reads (calibrated on k_upload_split in
-    profiles/README.md), so this is an upper bound for the 4-byte-per-lane part of the kernel's reads."""
+def committed_csv(suffix, kernel_substr):
+    """Row of the newest committed profiles/*<suffix> for the kernel (rocprofv3 --pmc runs of this command at 16 777 216)."""
     import csv
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic_pmc.csv")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*" + suffix)))
     if not files:
         return None, None
     for row in csv.DictReader(open(files[-1])):
         if kernel_substr in row["kernel"]:
-            return (2.0 * float(row["avg_FETCH_SIZE_raw"]) + float(row["avg_WRITE_SIZE_raw"])) * 1024.0, \
-                os.path.relpath(files[-1], ROOT) + " (16 777 216 particles)"
+            return row, os.path.relpath(files[-1], ROOT) + " (16 777 216 particles)"
     return None, None
+
+
+def pmc_traffic(kernel_substr):
+    """HBM bytes per launch of the dominant kernel (FETCH_SIZE and WRITE_SIZE in separate passes, KiB).  FETCH_SIZE is
+    doubled as MI355X_MICROARCH.md prescribes for wide streaming reads (calibrated on k_upload_split in
+    profiles/README.md), so this is an upper bound for the 4-byte-per-lane part of the kernel's reads."""
+    row, src = committed_csv("_hbm_traffic_pmc.csv", kernel_substr)
+    if row is None:
+        return None, None
+    return (2.0 * float(row["avg_FETCH_SIZE_raw"]) + float(row["avg_WRITE_SIZE_raw"])) * 1024.0, src
+
+
+def pmc_valu(kernel_substr):
+    """Executed wave-level vector instructions per launch of the dominant kernel (SQ_INSTS_VALU, per-launch median)."""
+    row, src = committed_csv("_sq_pmc.csv", kernel_substr)
+    if row is None:
+        return None, None, None
+    return float(row["SQ_INSTS_VALU"]), float(row.get("SQ_INSTS_VALU_TRANS_F32", 0) or 0), src
+
+
+def spawn_ranks(a):
+    """python bench.py --gpus N started plainly: N rank processes (children of a parent that never touches a GPU)."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(a.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), LOCAL_WORLD_SIZE=str(a.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out0, _ = procs[0].communicate()
+    rcs = [p.wait() for p in procs]
+    sys.stdout.write(out0 or "")
+    sys.stdout.flush()
+    sys.exit(max(rcs) if all(rc >= 0 for rc in rcs) else 1)
 
 
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(a)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if a.gpus != world:
-        if world == 1 and a.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
-    import torch
-    import torch.distributed as dist
+        sys.exit(f"bench.py --gpus {a.gpus} inside a torch.distributed.run world of {world} ranks")
 
     from sphfluidsimulation_amd import presets
 
@@ -116,7 +175,6 @@ def main():
         return
 
     from sphfluidsimulation_amd.simulation import SphFluidSimulation
-    torch.cuda.set_device(0)
     pos0, vel0 = presets.dam_break(n, fill, a.seed)
     sim = SphFluidSimulation(particleNumber=n, bucketResolution=R, damFillRate=fill, viscosity=0.01,
                              restDensity=1.5, gasConstant=150.0, stiffnessCoefficient=5000.0,
@@ -124,21 +182,21 @@ def main():
 
     # GPU result after CPU_FRAMES frames, checked against the CPU baseline run below; then start over for the timing
     warm = a.warmup
-    frame1 = None
+    parity_state = None
     if not a.no_cpu_baseline:
         for _ in range(CPU_FRAMES):
             sim.Update(dt_frame)
-        frame1 = sim.download()
+        parity_state = sim.download()
         sim.upload(pos0, vel0)
     sim.step_n(dt_frame, warm)
     sim.synchronize()
     sim.reset_stats()
 
-    torch.cuda.synchronize()
     t0 = time.perf_counter()
     sim.step_n(dt_frame, a.steps)
-    torch.cuda.synchronize()
+    sim.synchronize()
     elapsed = time.perf_counter() - t0
+    frames_done = warm + a.steps
 
     st = sim.stats()
     # SURVEY.md 8d asks for median and mean: a few more frames, each synchronised and timed on its own (never part of `value`)
@@ -149,6 +207,7 @@ def main():
         sim.Update(dt_frame)
         sim.synchronize()
         singles.append((time.perf_counter() - ts) * 1e3)
+    frames_done += len(singles)
     # row f3, the render feed after the path (UpdateMeshProperties, never part of `value`): 112 B per particle
     sim.UpdateMeshProperties()
     sim.synchronize()
@@ -157,6 +216,34 @@ def main():
         sim.UpdateMeshProperties()
     sim.synchronize()
     mesh_ms = (time.perf_counter() - tm) * 1e3 / 20
+    extras = {}
+    if not a.no_extras:
+        # the dam collapses: cells fill up, the calm boxes the neighbour lists live on shrink (never part of `value`)
+        late_to = 300
+        if frames_done < late_to - 20:
+            sim.step_n(dt_frame, late_to - 20 - frames_done)
+            sim.synchronize()
+            tl = time.perf_counter()
+            sim.step_n(dt_frame, 20)
+            sim.synchronize()
+            late = time.perf_counter() - tl
+            ls = sim.stats()
+            extras["late_phase"] = {"frames": f"{late_to - 19}-{late_to}", "ms_per_step": late * 1e3 / 20,
+                                    "particle_steps_per_s": n * 20 / late, "max_cell_occupancy": ls["max_cell_occupancy"],
+                                    "queued_targets_last_sweep": ls["queued_targets"]}
+        # S = 1 (one sub-step per grid build, what conventional SPH codes do): from the initial state again
+        sim.upload(pos0, vel0)
+        sim.substeps = 1
+        sim.set_params()
+        sim.step_n(dt_frame, warm)
+        sim.synchronize()
+        t1 = time.perf_counter()
+        sim.step_n(dt_frame, a.steps)
+        sim.synchronize()
+        e1 = time.perf_counter() - t1
+        extras["s1_variant"] = {"substeps": 1, "ms_per_step": e1 * 1e3 / a.steps, "particle_steps_per_s": n * a.steps / e1}
+        sim.substeps = 5
+        sim.set_params()
     # boundary cost when the caller hands over HOST arrays every frame (never part of `value`)
     t1 = time.perf_counter()
     sim.upload(pos0, vel0)
@@ -171,8 +258,15 @@ def main():
     kernel = "k_velpos_list" if listed else "k_velpos_brick"
     kernel_ms = st["ms_velpos_list"] / st["launches_velpos_list"] if listed else vel_ms
     achieved = BYTES_PER_SUBSTEP * n / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
-    valu_tflops = value * pbar * (FLOPS_DENSITY + FLOPS_FORCE * 5) / 1e12
     traffic, traffic_src = pmc_traffic(kernel) if n == 16777216 else (None, None)
+    insts, trans, insts_src = pmc_valu(kernel) if n == 16777216 else (None, None, None)
+    # transcendental instructions (v_rcp, v_sqrt) hold the issue port four times as long as the rest
+    issue_frac = ((insts + 3.0 * trans) / (kernel_ms * 1e-3) / VALU_ISSUE_PEAK) if insts and kernel_ms > 0 else None
+    hbm_frac = achieved / HBM_PEAK_GBS
+    # executed pair work: list entries walked (5 sub-steps) + candidates scanned by the density pass
+    entries_per_frame = st["list_entries"] / max(a.steps, 1)
+    exec_flops = (entries_per_frame * FLOPS_FORCE + st["candidates_density"] * FLOPS_DENSITY) / (ms_per_step * 1e-3) if listed else \
+        value * pbar * (FLOPS_DENSITY + FLOPS_FORCE * 5)
     out = {
         "metric": "particle-steps/s", "value": value, "unit": "particle-steps/s", "n_gpus": 1,
         "steps": a.steps, "warmup": warm, "ms_per_step": ms_per_step, "higher_is_better": True,
@@ -180,12 +274,14 @@ def main():
         "config": {"workload": workload, "particles": n, "bucket_resolution": R, "substeps": 5,
                    "mode": "exact_order"},
         "roofline": {
-            "bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS,
-            "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+            "bound": "valu" if (issue_frac or 0.0) > hbm_frac else "hbm", "kernel": kernel, "achieved": achieved,
+            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_frac, "traffic": traffic, "traffic_source": traffic_src,
             "algorithmic_bytes_per_launch": BYTES_PER_SUBSTEP * n,
             "kernel_ms": kernel_ms, "launches": st["launches_velpos_list"] if listed else st["launches_velpos"],
-            "step_hbm_frac": value * BYTES_PER_STEP / (HBM_PEAK_GBS * 1e9),
-            "valu_frac": valu_tflops / VALU_PEAK_TFLOPS,
+            "step_hbm_frac": value * (32 + 52 * 5) / (HBM_PEAK_GBS * 1e9),
+            "valu_issue_frac": issue_frac, "valu_insts_per_launch": insts, "valu_source": insts_src,
+            "valu_frac_executed_pair_flops": exec_flops / 1e12 / VALU_PEAK_TFLOPS,
+            "valu_frac_nominal_candidates": value * pbar * (FLOPS_DENSITY + FLOPS_FORCE * 5) / 1e12 / VALU_PEAK_TFLOPS,
             "candidates_per_particle": pbar,
         },
         "passes_ms": {"grid": st["ms_grid"] / max(st["launches_grid"], 1),
@@ -206,13 +302,13 @@ def main():
         "max_cell_occupancy": st["max_cell_occupancy"], "nan_resets": st["nan_resets"],
         "queued_targets_last_sweep": st["queued_targets"],
     }
+    out.update(extras)
     if not a.no_cpu_baseline:
         base, (po, vo, ro) = cpu_baseline(n, R, fill, pos0, vel0, dt_frame)
         out["cpu_baseline"] = base
         out["parity_frames"] = CPU_FRAMES
-        out["parity_frame1_max_abs_diff"] = {   # (key kept from round 1; the state compared is the one after parity_frames)
-            "pos": float(np.abs(frame1[0] - po).max()), "vel": float(np.abs(frame1[1] - vo).max()),
-            "rho": float(np.abs(frame1[2] - ro).max())}
+        out["parity_max_abs_diff"] = {"pos": float(np.abs(parity_state[0] - po).max()), "vel": float(np.abs(parity_state[1] - vo).max()),
+                                      "rho": float(np.abs(parity_state[2] - ro).max())}
     sim.OnDestroy()
     print(json.dumps(out), flush=True)
 

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define SPH_ABI_VERSION 1
+#define SPH_ABI_VERSION 2
 
 #define SPH_OK 0
 #define SPH_E_INVALID_ARG (-1)
@@ -67,8 +67,18 @@ typedef struct SphParams {
     float gravity[3];           /* (0,-9.8,0) VelPos.compute:7                                      */
     uint32_t precision;         /* 0 = fp32 state (only value supported in this ABI version)        */
     uint32_t exact_order;       /* 1 = accumulate neighbours in the reference's x,y,z / slot order  */
-    int32_t device_id;          /* HIP device ordinal                                               */
+    int32_t device_id;          /* HIP device ordinal (num_devices <= 1)                            */
     uint32_t flags;             /* SPH_FLAG_*                                                       */
+    /* ---- ABI version 2 ---- */
+    uint32_t num_devices;       /* 0 or 1: one GPU (device_id).  2..8: the particle set is split into that many z-slabs
+                                   inside THIS process, slab i on device_ids[i], halo exchange over RCCL/xGMI from inside
+                                   the library; sph_upload / sph_step / sph_download / sph_get_stats work unchanged      */
+    int32_t device_ids[8];      /* HIP ordinals of the slabs' devices, ascending z.  Repeated ordinals are allowed (several
+                                   slabs on one GPU: rehearsal; the exchange is then a device copy, not RCCL)              */
+    uint32_t halo_planes;       /* ghost planes per slab face to start with (0 = default 2); doubled automatically, and the
+                                   frame re-run, whenever a particle outruns them (SphStats.frames_rerun)                 */
+    float list_skin;            /* neighbour-list radius = h * (1 + list_skin); 0 = default 0.04 (tuning; any value in
+                                   (0, 1] gives the same results)                                                          */
 } SphParams;
 
 #define SPH_FLAG_PROFILE 1u     /* record HIP events around every pass (SphStats.ms_*)            */
@@ -76,6 +86,7 @@ typedef struct SphParams {
 #define SPH_FLAG_NO_LISTS 4u    /* diagnostic: every sub-step re-scans its 27 bins (no frame-coherent neighbour lists) */
 #define SPH_FLAG_LISTS_ALWAYS 16u /* diagnostic: record neighbour lists every frame (default: only while they pay, see
                                     SphStats.frames_without_lists) */
+#define SPH_FLAG_PEER_COPIES 32u /* multi-device context: move the halo with peer-to-peer device copies instead of RCCL */
 #define SPH_FLAG_NO_GRAPHS 8u   /* diagnostic: sph_step issues its ~60 launches every frame instead of replaying a HIP graph */
 
 /* Values of the uniforms the reference pushes through ShaderIDs.cs:5-32. */
@@ -118,6 +129,10 @@ typedef struct SphStats {
     uint64_t launches_velpos_list;
     uint64_t graph_replays;           /* sph_step frames replayed from a captured HIP graph since create         */
     uint64_t frames_without_lists;    /* sph_step frames the list policy ran without recording (lists would not pay) */
+    /* z-slab mode (several GPUs), since the last sph_reset_stats */
+    uint64_t host_syncs;              /* host <-> device synchronisations issued by slab frames (one per frame)  */
+    uint64_t frames_rerun;            /* frames run again with a wider halo after a violation                     */
+    uint64_t halo_planes;             /* ghost planes per face in use now                                         */
 } SphStats;
 
 typedef struct SphContext SphContext;
@@ -195,46 +210,68 @@ int sph_synchronize(SphContext *ctx);
 /* Run on a caller-owned hipStream_t (e.g. torch's current stream) instead of the context's own. */
 int sph_set_stream(SphContext *ctx, void *hip_stream);
 
+/* Which native libraries this process bound the engine to (diagnostics: a host that maps a second HIP runtime image --
+ * e.g. one bundled with another plugin -- must hand file descriptors and pointers to THIS one). */
+typedef struct SphRuntimeInfo {
+    uint32_t struct_size;         /* = sizeof(SphRuntimeInfo) */
+    int32_t hip_runtime_version;  /* hipRuntimeGetVersion */
+    int32_t hip_driver_version;   /* hipDriverGetVersion  */
+    int32_t device_count;
+    int32_t rccl_version;         /* 0 while no RCCL image is mapped (the library loads it only when a transport needs it) */
+    char hip_library_path[256];   /* image that implements this library's hip* calls (dladdr) */
+    char rccl_library_path[256];
+} SphRuntimeInfo;
+int sph_runtime_info(SphRuntimeInfo *out);
+
+/* Numerics self-test on the device: the shared-reciprocal quotients and the unscaled square root the pair kernels use
+ * (csrc/sph_fastdiv.hpp) against the IEEE division / sqrtf instruction sequences, on n pseudo-random operand sets covering the
+ * window in which the kernels use them.  mismatches[4] = {quotient, quotient by a doubled denominator, square root, window
+ * test}; all zero on a correct build. */
+int sph_selftest_arithmetic(int device_id, uint64_t n, uint64_t seed, uint64_t mismatches[4]);
+
 /*
- * ---- z-slab domain decomposition: one process per GPU (new work; the reference is single-GPU) ----
- * A slab context holds the particles whose BUCKET ROW (Bucket.compute:26-29) lies in the grid planes
- * cz in [z_lo, z_hi) plus "ghost" copies of halo_w planes on either side.  The host side (Python,
- * sphfluidsimulation_amd/distributed.py) sequences one frame and moves the buffers between ranks
- * with torch.distributed (RCCL over xGMI): nothing below communicates by itself.
+ * ---- z-slab domain decomposition, one process per GPU (new work; the reference is single-GPU) ----
+ * (In ONE process, SphParams.num_devices does all of this behind sph_create / sph_step.)
+ * A slab context holds the particles whose BUCKET ROW (Bucket.compute:26-29) lies in the grid planes cz in [z_lo, z_hi) of
+ * slab `rank` of `world` (sph_slab_planes) plus "ghost" copies of halo planes on either side.  sph_slab_step runs one
+ * Update() of the slab INCLUDING the exchange with its two z-neighbours (protocol: csrc/sph_slab_frame.hip):
  *
- *   begin_frame -> [exchange migrants] -> append(owned) -> export_ghosts -> [exchange ghosts]
- *   -> append(ghost) -> sph_bucket_generation -> sph_density_calculation
- *   -> pack_update(RHO) -> [exchange] -> unpack_update(RHO)
- *   -> substeps x { sph_update_velocity_and_position ; pack_update(POSVEL) -> [exchange] -> unpack }
+ *   sph_slab_create -> sph_slab_configure(rank, world) -> sph_slab_comm_init (RCCL; id from sph_comm_unique_id on rank 0,
+ *   distributed by the host) or sph_slab_set_host_transport -> sph_slab_upload -> sph_slab_step ... -> sph_slab_download
  *
- * send / recv arguments are DEVICE pointers owned by the caller (e.g. torch tensors):
- * particle records are 9 fp32 words (x y z rho vx vy vz vel.w id), RHO updates 1 word, POSVEL
- * updates 7 words (x y z rho vx vy vz), in the sender's export order.
+ * sph_slab_step / sph_slab_finish / sph_slab_download / sph_get_stats are COLLECTIVE: every rank calls them in the same
+ * order.  A frame returns enqueued after ONE host synchronisation; whether its halo held is known at the next collective
+ * call, which re-runs it with a wider halo if not (bit-identical to the single-GPU result either way).
  * SphParams.num_particles stays the GLOBAL particle count (mass and sentinel depend on it).
  */
 #define SPH_SLAB_UPDATE_RHO 0
 #define SPH_SLAB_UPDATE_POSVEL 1
-#define SPH_SLAB_RECORD_WORDS 9
-#define SPH_SLAB_POSVEL_WORDS 7
+#define SPH_COMM_ID_BYTES 128
 
 int sph_slab_create(const SphParams *params, uint32_t local_capacity, SphContext **out);
-int sph_slab_configure(SphContext *ctx, int z_lo, int z_hi, int halo_w, int has_left, int has_right);
+/* [z_lo, z_hi) of slab `rank`: bucket_resolution planes split as evenly as possible (the rule every rank must share). */
+int sph_slab_planes(uint32_t bucket_resolution, int world, int rank, int *z_lo, int *z_hi);
+int sph_slab_configure(SphContext *ctx, int rank, int world);
+/* RCCL transport: rank 0 makes the id, the host hands the 128 bytes to every rank (e.g. a torch.distributed broadcast). */
+int sph_comm_unique_id(void *id_bytes);
+int sph_slab_comm_init(SphContext *ctx, const void *id_bytes);
+/* Host transport: the library stages the messages through pinned host memory and calls back (blocking) to move them:
+ * exchange sends the two buffers to the left / right neighbour and fills the two receive buffers (sizes may be 0);
+ * allreduce replaces *value by its sum over all ranks.  Both return 0 on success. */
+typedef int (*SphHostExchangeFn)(void *user, const void *send_left, size_t send_left_bytes, const void *send_right,
+                                 size_t send_right_bytes, void *recv_left, size_t recv_left_bytes, void *recv_right,
+                                 size_t recv_right_bytes);
+typedef int (*SphHostAllreduceFn)(void *user, unsigned long long *value);
+int sph_slab_set_host_transport(SphContext *ctx, SphHostExchangeFn exchange, SphHostAllreduceFn allreduce, void *user);
 /* n owned particles of this rank with their global ids (host arrays); vel4 may be NULL. */
 int sph_slab_upload(SphContext *ctx, uint32_t n, const float *pos4, const float *vel4, const uint32_t *ids);
-/* Drops last frame's ghosts, keeps what is still binned in this slab, packs what left it.
- * counts = {kept, to_left, to_right}.  Synchronises. */
-int sph_slab_begin_frame(SphContext *ctx, void *send_left, void *send_right, uint32_t cap_records, uint32_t counts[3]);
-/* Appends received particle records as owned (as_ghost = 0, after migration) or as ghosts (1). */
-int sph_slab_append(SphContext *ctx, const void *recv_left, uint32_t n_left, const void *recv_right, uint32_t n_right,
-                    int as_ghost);
-/* Packs the owned particles binned in the halo_w boundary planes of each face.
- * counts = {to_left, to_right}.  Synchronises. */
-int sph_slab_export_ghosts(SphContext *ctx, void *send_left, void *send_right, uint32_t cap_records, uint32_t counts[2]);
-int sph_slab_pack_update(SphContext *ctx, int what, void *send_left, void *send_right);
-int sph_slab_unpack_update(SphContext *ctx, int what, const void *recv_left, const void *recv_right);
-/* out = {owned, ghosts_from_left, ghosts_from_right, exported_to_left, exported_to_right}. */
+/* One Update() (SphFluidSimulation.cs:96-102) of this slab with Time.deltaTime = delta_time. */
+int sph_slab_step(SphContext *ctx, float delta_time);
+/* Validates the frame in flight (re-running it if its halo was violated): the state is final afterwards. */
+int sph_slab_finish(SphContext *ctx);
+/* out = {owned, ghosts_from_left, ghosts_from_right, refreshed_for_left, refreshed_for_right} of the last frame. */
 int sph_slab_counts(SphContext *ctx, uint32_t out[5]);
-/* Owned particles in arbitrary order with their ids; pos.w is 1 before the first sub-step. */
+/* Owned particles in arbitrary order with their ids; pos.w is 1 before the first sub-step.  Calls sph_slab_finish. */
 int sph_slab_download(SphContext *ctx, uint32_t cap, uint32_t *ids, float *pos4, float *vel4, float *rho,
                       uint32_t *n_out);
 

@@ -20,10 +20,10 @@ SPH_FLAG_NO_TILING = 2
 SPH_FLAG_NO_LISTS = 4
 SPH_FLAG_NO_GRAPHS = 8
 SPH_FLAG_LISTS_ALWAYS = 16
+SPH_FLAG_PEER_COPIES = 32
+SPH_COMM_ID_BYTES = 128
 SPH_SLAB_UPDATE_RHO = 0
 SPH_SLAB_UPDATE_POSVEL = 1
-SPH_SLAB_RECORD_WORDS = 9
-SPH_SLAB_POSVEL_WORDS = 7
 
 _ERR_NAMES = {
     SPH_E_INVALID_ARG: "SPH_E_INVALID_ARG", SPH_E_BAD_STATE: "SPH_E_BAD_STATE", SPH_E_OOM: "SPH_E_OOM",
@@ -56,6 +56,11 @@ class SphParams(C.Structure):
         ("exact_order", C.c_uint32),
         ("device_id", C.c_int32),
         ("flags", C.c_uint32),
+        # ABI version 2
+        ("num_devices", C.c_uint32),
+        ("device_ids", C.c_int32 * 8),
+        ("halo_planes", C.c_uint32),
+        ("list_skin", C.c_float),
     ]
 
 
@@ -97,6 +102,9 @@ class SphStats(C.Structure):
         ("launches_velpos_list", C.c_uint64),
         ("graph_replays", C.c_uint64),
         ("frames_without_lists", C.c_uint64),
+        ("host_syncs", C.c_uint64),
+        ("frames_rerun", C.c_uint64),
+        ("halo_planes", C.c_uint64),
     ]
 
     def as_dict(self):
@@ -114,6 +122,24 @@ class SphMeshParams(C.Structure):
 
 
 SPH_MESH_RECORD_FLOATS = 20
+
+
+class SphRuntimeInfo(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32),
+        ("hip_runtime_version", C.c_int32),
+        ("hip_driver_version", C.c_int32),
+        ("device_count", C.c_int32),
+        ("rccl_version", C.c_int32),
+        ("hip_library_path", C.c_char * 256),
+        ("rccl_library_path", C.c_char * 256),
+    ]
+
+
+# host transport callbacks (sph_slab_set_host_transport)
+HOST_EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
+                               C.c_void_p, C.c_size_t)
+HOST_ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_ulonglong))
 
 # every symbol include/sph_hip.h declares: name -> (restype, argtypes)
 _FP = C.POINTER(C.c_float)
@@ -141,14 +167,17 @@ SYMBOLS = {
     "sph_reset_stats": (C.c_int, [_CTX]),
     "sph_synchronize": (C.c_int, [_CTX]),
     "sph_set_stream": (C.c_int, [_CTX, C.c_void_p]),
+    "sph_runtime_info": (C.c_int, [C.POINTER(SphRuntimeInfo)]),
+    "sph_selftest_arithmetic": (C.c_int, [C.c_int, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64)]),
     "sph_slab_create": (C.c_int, [C.POINTER(SphParams), C.c_uint32, C.POINTER(_CTX)]),
-    "sph_slab_configure": (C.c_int, [_CTX, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "sph_slab_planes": (C.c_int, [C.c_uint32, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "sph_slab_configure": (C.c_int, [_CTX, C.c_int, C.c_int]),
+    "sph_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "sph_slab_comm_init": (C.c_int, [_CTX, C.c_void_p]),
+    "sph_slab_set_host_transport": (C.c_int, [_CTX, HOST_EXCHANGE_FN, HOST_ALLREDUCE_FN, C.c_void_p]),
     "sph_slab_upload": (C.c_int, [_CTX, C.c_uint32, _FP, _FP, C.POINTER(C.c_uint32)]),
-    "sph_slab_begin_frame": (C.c_int, [_CTX, C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]),
-    "sph_slab_append": (C.c_int, [_CTX, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_int]),
-    "sph_slab_export_ghosts": (C.c_int, [_CTX, C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]),
-    "sph_slab_pack_update": (C.c_int, [_CTX, C.c_int, C.c_void_p, C.c_void_p]),
-    "sph_slab_unpack_update": (C.c_int, [_CTX, C.c_int, C.c_void_p, C.c_void_p]),
+    "sph_slab_step": (C.c_int, [_CTX, C.c_float]),
+    "sph_slab_finish": (C.c_int, [_CTX]),
     "sph_slab_counts": (C.c_int, [_CTX, C.POINTER(C.c_uint32)]),
     "sph_slab_download": (C.c_int, [_CTX, C.c_uint32, C.POINTER(C.c_uint32), _FP, _FP, _FP, C.POINTER(C.c_uint32)]),
     "sph_last_error": (C.c_char_p, [_CTX]),
@@ -178,6 +207,15 @@ def check(rc: int, ctx=None):
     if rc != SPH_OK:
         msg = lib().sph_last_error(ctx)
         raise SphError(rc, msg.decode() if msg else "")
+
+
+def runtime_info() -> dict:
+    info = SphRuntimeInfo()
+    info.struct_size = C.sizeof(SphRuntimeInfo)
+    check(lib().sph_runtime_info(C.byref(info)))
+    return {"hip_runtime_version": info.hip_runtime_version, "hip_driver_version": info.hip_driver_version,
+            "device_count": info.device_count, "rccl_version": info.rccl_version,
+            "hip_library_path": info.hip_library_path.decode(), "rccl_library_path": info.rccl_library_path.decode()}
 
 
 def default_params() -> SphParams:

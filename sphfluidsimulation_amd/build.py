@@ -17,13 +17,15 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIB_DIR, "libsph_hip.so")
-SOURCES = ["sph_engine.hip", "sph_kernels_grid.hip", "sph_kernels_sweep.hip", "sph_kernels_brick_density.hip", "sph_kernels_brick_velpos.hip", "sph_kernels_slab.hip", "sph_kernels_init.hip", "sph_kernels_mesh.hip", "sph_kernels_list.hip"]
-HEADERS = ["sph_internal.hpp", "sph_sweep_common.hpp", "sph_brick_impl.inc", os.path.join("..", "..", "include", "sph_hip.h")]
+SOURCES = ["sph_engine.hip", "sph_kernels_grid.hip", "sph_kernels_sweep.hip", "sph_kernels_brick_density.hip", "sph_kernels_brick_velpos.hip", "sph_kernels_slab.hip", "sph_kernels_init.hip", "sph_kernels_mesh.hip", "sph_kernels_list.hip", "sph_kernels_selftest.hip", "sph_slab_frame.hip"]
+HEADERS = ["sph_internal.hpp", "sph_sweep_common.hpp", "sph_fastdiv.hpp", "sph_context.hpp", "sph_brick_impl.inc", os.path.join("..", "..", "include", "sph_hip.h")]
 FLAGS = [
-    "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+    "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
     "-ffp-contract=off", "-fno-fast-math", "-fhip-fp32-correctly-rounded-divide-sqrt",
     "-Wall", "-Wno-unused-function",
 ]
+
+LINK_LIBS = ["-ldl"]
 
 
 def hipcc() -> str:
@@ -45,11 +47,27 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not needs_build():
         return LIB
     os.makedirs(LIB_DIR, exist_ok=True)
+    obj_dir = os.path.join(LIB_DIR, "obj")
+    os.makedirs(obj_dir, exist_ok=True)
     extra = os.environ.get("SPH_HIPCC_EXTRA", "").split()   # diagnostic builds, e.g. -DSPH_ABLATE=1
-    cmd = [hipcc()] + FLAGS + extra + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB]
+    cc = hipcc()
+    # one hipcc per translation unit, in parallel (8 host cores here, 16 on the GPU box), then one link
+    procs = []
+    for src in SOURCES:
+        obj = os.path.join(obj_dir, os.path.splitext(src)[0] + ".o")
+        cmd = [cc] + FLAGS + extra + ["-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        procs.append((cmd, obj, subprocess.Popen(cmd)))
+    objs = []
+    for cmd, obj, pr in procs:
+        if pr.wait() != 0:
+            raise subprocess.CalledProcessError(pr.returncode, cmd)
+        objs.append(obj)
+    link = [cc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + LINK_LIBS + ["-o", LIB]
     if verbose:
-        print(" ".join(cmd), flush=True)
-    subprocess.check_call(cmd)
+        print(" ".join(link), flush=True)
+    subprocess.check_call(link)
     return LIB
 
 

@@ -1,7 +1,6 @@
 // Host side of libsph_hip.so: context, device memory, the frame schedule of
 // SphFluidSimulation.cs::Update (:96-102) and the C ABI declared in include/sph_hip.h.
-#include "../../include/sph_hip.h"
-#include "sph_internal.hpp"
+#include "sph_context.hpp"
 
 #include <limits.h>
 #include <math.h>
@@ -15,120 +14,7 @@
 
 using namespace sph;
 
-static thread_local std::string g_last_error = "";
-
-struct PassEvents {
-    hipEvent_t a, b;
-    int kind;  // 0 grid, 1 density, 2 velpos (whole pass), 3 k_velpos_list alone
-};
-
-struct SphContext {
-    SphParams params{};
-    SphDerived derived{};
-    Dev dev{};
-    int device = 0;
-    hipStream_t stream = nullptr;
-    bool own_stream = false;
-    std::vector<void *> allocs;
-    // staging in the reference's texture layout
-    float4 *pos4_dev = nullptr, *vel4_dev = nullptr;
-    float *rho_id_dev = nullptr, *pw0 = nullptr;
-    // One frame (grid build, density pass, S sub-steps: ~60 launches) captured as a HIP graph and replayed: for scenes of the
-    // reference's own size (262 144 particles, ~2 ms per frame) the launches cost as much as a third of the frame.
-    // The device pointers a frame starts from alternate with period 2 (id / id_nxt and the wild-velocity slot flip once per
-    // frame), so there are two graphs; each remembers the launch state (Dev) it was captured for and is re-captured when
-    // that no longer matches (sph_set_params, another sub-step count).  delta_time is read from device memory.
-    struct FrameGraph {
-        hipGraphExec_t exec = nullptr;
-        Dev start{};                  // launch state at frame start
-        uint32_t substeps = 0;
-        bool recorded_lists = false;  // the captured density pass recorded neighbour lists
-        bool lists_on = false;        // neighbour lists were enabled and allocated at capture time
-    } graph[2];
-    bool graphs_enabled = false;
-    float *dt_dev = nullptr;          // delta_time / dt_divisor of the frame being replayed (device scalar)
-    uint64_t frames_since_upload = 0, graph_replays = 0;
-    // frame-coherent neighbour lists (sph_kernels_list.hip)
-    bool nl_enabled = false, nl_allocated = false;
-    bool nl_fresh = false;            // the grid was just built: the next density pass runs on the binned positions
-    bool nl_recorded = false;         // ... and recorded the lists the VelPos sub-steps of this frame may use
-    // List policy.  Recording lists and keeping them valid costs ~25 % of a scanning frame at 16.7 M -- where 99 % of the
-    // target sub-steps are then served three times faster -- but makes a frame of the reference's own 262 144-particle
-    // scene 1.5x slower (a box that small is all wall layer, 28 % served; its kernels are latency-bound, every extra
-    // launch counts).  k_frame_report publishes, frame by frame, how many target sub-steps the lists served; below 90 %
-    // (two reports in a row) the engine stops recording and probes again after a back-off that doubles with every
-    // failed probe.
-    volatile unsigned long long *report_host = nullptr;   // mapped pinned memory, written by the device
-    unsigned long long *report_dev = nullptr;
-    unsigned long long pol_seen[3] = {0, 0, 0};
-    bool pol_on = true;               // this frame records lists
-    bool pol_confirmed = false;       // two good reports since recording was (re)started: until then the host does not run
-                                      // more than two frames ahead of the reports (a caller queueing 20 frames would
-                                      // otherwise pay for 20 frames of a probe that fails)
-    unsigned long long pol_issued = 0;   // frames issued with a report kernel
-    int pol_low_streak = 0, pol_high_streak = 0;
-    uint64_t pol_backoff = 8, pol_resume_at = 0, pol_frames_off = 0;
-    float nl_skin_frac = 0.04f;       // skin / h (profiles/: 0.04-0.06 is the optimum of the 16.7 M dam break)
-    float4 *mesh_props = nullptr;     // _particleMeshPropertiesBuffer (:174), allocated on first use
-    bool mesh_valid = false;
-    // row f4: the same buffer in exportable device memory (HIP virtual-memory allocation), once a caller asked for its fd
-    hipMemGenericAllocationHandle_t mesh_handle{};
-    void *mesh_va = nullptr;
-    size_t mesh_va_size = 0;
-    bool uploaded = false, grid_valid = false;
-    int substeps_since_upload = 0;
-    float dt_last = 0.0f;
-    uint64_t frames = 0, substeps = 0;
-    // profiling
-    bool profile = false;
-    std::vector<PassEvents> pending;
-    std::vector<hipEvent_t> free_events;
-    double ms[4] = {0, 0, 0, 0};
-    uint64_t launches[4] = {0, 0, 0, 0};
-    std::string last_error;
-    // z-slab (multi-GPU) mode
-    bool slab = false;
-    uint32_t capacity = 0;            // particles the device arrays can hold
-    int z_lo = 0, z_hi = 0, halo_w = 2, has_left = 0, has_right = 0;
-    uint32_t n_ghost[2] = {0, 0};     // ghosts appended this frame (from left, from right)
-    uint32_t n_export[2] = {0, 0};    // owned particles exported as ghosts this frame (to left, to right)
-    uint32_t *send_src[2] = {nullptr, nullptr};
-    uint32_t *slab_counters = nullptr;  // 4 words, see k_slab_classify
-    uint32_t *ids_dev = nullptr;
-};
-
-// A new particle set: the list policy starts over.  Prior: in a box of fewer than ~100 cells per axis most bricks lie
-// within reach of the wall layer, whose particles the wall force scatters by more than any useful skin -- such scenes
-// start without lists and probe late; large boxes start with lists.
-static void reset_list_policy(SphContext *c)
-{
-    const bool big = c->dev.R >= 100u;
-    c->pol_on = big || (c->params.flags & SPH_FLAG_LISTS_ALWAYS);
-    c->pol_confirmed = false;
-    c->pol_low_streak = c->pol_high_streak = 0;
-    c->pol_backoff = big ? 8 : 32;
-    c->pol_resume_at = c->frames + (c->pol_on ? 0 : c->pol_backoff);
-}
-
-static int fail(SphContext *ctx, int code, const char *fmt, ...)
-{
-    char buf[512];
-    va_list ap;
-    va_start(ap, fmt);
-    vsnprintf(buf, sizeof buf, fmt, ap);
-    va_end(ap);
-    if (ctx) ctx->last_error = buf;
-    g_last_error = buf;
-    return code;
-}
-
-#define HIP_TRY(ctx, expr)                                                                      \
-    do {                                                                                        \
-        hipError_t _e = (expr);                                                                 \
-        if (_e != hipSuccess)                                                                   \
-            return fail(ctx, _e == hipErrorOutOfMemory ? SPH_E_OOM : SPH_E_HIP, "%s: %s", #expr, \
-                        hipGetErrorString(_e));                                                 \
-    } while (0)
+thread_local std::string g_last_error = "";
 
 // ---- derived parameters: SphFluidSimulation.cs:84-85,159,176,236-237,255 -------
 
@@ -154,7 +40,7 @@ static void derive(const SphParams &p, SphDerived *d)
     d->effective_radius6 = (float)pow((double)d->effective_radius, 6.0); // :255
 }
 
-static void refresh_scalars(SphContext *c)
+void refresh_scalars(SphContext *c)
 {
     const SphParams &p = c->params;
     const SphDerived &dv = c->derived;
@@ -184,11 +70,8 @@ static void refresh_scalars(SphContext *c)
     d.use_bricks = (p.flags & SPH_FLAG_NO_TILING) ? 0u : 1u;
     // neighbour lists: skin = nl_skin_frac * h; pre-filter radius (h + skin)^2 rounded up like h2_up; a brick is calm
     // while its relative-displacement bound stays below 90 % of the skin (the rest absorbs fp32 rounding of the bound)
-    c->nl_enabled = d.use_bricks && !(p.flags & SPH_FLAG_NO_LISTS) && d.R <= 256u;
-    if (const char *e = getenv("SPH_NL_SKIN")) {   // tuning aid: skin / h
-        const float v = (float)atof(e);
-        if (v > 0.0f && v <= 1.0f) c->nl_skin_frac = v;
-    }
+    c->nl_enabled = d.use_bricks && !(p.flags & SPH_FLAG_NO_LISTS) && d.R <= 256u && !c->nl_unavailable;
+    c->nl_skin_frac = p.list_skin > 0.0f ? p.list_skin : 0.04f;   // (profiles/: 0.04-0.06 is the optimum of the 16.7 M dam break)
     {
         const double hs = (double)d.h * (1.0 + (double)c->nl_skin_frac);
         d.h2_list = nextafterf((float)(hs * hs * (1.0 + 1e-5)), INFINITY);
@@ -218,6 +101,9 @@ static int validate(SphContext *ctx, const SphParams *p)
     if (!(p->dt_divisor > 0.0f)) return fail(ctx, SPH_E_INVALID_ARG, "dt_divisor must be > 0");
     if (p->precision != 0) return fail(ctx, SPH_E_UNSUPPORTED, "precision %u not supported (fp32 only)", p->precision);
     if (p->exact_order != 1) return fail(ctx, SPH_E_UNSUPPORTED, "exact_order=0 (fast mode) is not built in this version");
+    if (p->num_devices > 8) return fail(ctx, SPH_E_INVALID_ARG, "num_devices %u > 8", p->num_devices);
+    if (p->halo_planes > 128) return fail(ctx, SPH_E_INVALID_ARG, "halo_planes %u > 128", p->halo_planes);
+    if (!(p->list_skin >= 0.0f && p->list_skin <= 1.0f)) return fail(ctx, SPH_E_INVALID_ARG, "list_skin must be in [0, 1]");
     return SPH_OK;
 }
 
@@ -301,6 +187,7 @@ static void ensure_lists(SphContext *c)
     const size_t n = c->capacity;
     if (n == 0 || n >= (1u << kNlSlotBits)) {
         c->nl_enabled = false;
+        c->nl_unavailable = true;
         return;
     }
     const size_t bricks = (size_t)nl_bricks_x(d.R) * nl_bricks_y(d.R) * nl_bricks_z(d.R);
@@ -328,13 +215,14 @@ static void ensure_lists(SphContext *c)
         d.brick_state = nullptr;
         d.cur.p4 = d.nxt.p4 = nullptr;
         c->nl_enabled = false;
+        c->nl_unavailable = true;     // (sticky: a later sph_set_params must not try the multi-GB allocation again)
         c->last_error.clear();
         return;
     }
     c->nl_allocated = true;
 }
 
-static int do_bucket_generation(SphContext *c)
+int do_bucket_generation(SphContext *c)
 {
     if (!c->uploaded) return fail(c, SPH_E_BAD_STATE, "BucketGeneration before sph_upload");
     if (c->pol_on) ensure_lists(c);   // (several GB at 16.7 M: only once a frame is going to record)
@@ -354,7 +242,7 @@ static int do_bucket_generation(SphContext *c)
     return SPH_OK;
 }
 
-static int do_density(SphContext *c)
+int do_density(SphContext *c)
 {
     if (!c->grid_valid) return fail(c, SPH_E_BAD_STATE, "DensityCalculation before BucketGeneration");
     // the density pass of a fresh grid sees every particle where it was binned: it records the neighbour lists
@@ -369,7 +257,7 @@ static int do_density(SphContext *c)
     return SPH_OK;
 }
 
-static int do_velpos(SphContext *c, float dt)
+int do_velpos(SphContext *c, float dt)
 {
     if (!c->grid_valid) return fail(c, SPH_E_BAD_STATE, "UpdateVelocityAndPosition before BucketGeneration");
     c->dev.dt = dt;
@@ -511,9 +399,7 @@ static int create_common(const SphParams *params, uint32_t capacity, bool slab, 
         A(dalloc(c, &d.ghost, n));
         A(dalloc(c, &d.ghost_nxt, n));
         A(dalloc(c, &d.slot_of_src, n));
-        A(dalloc(c, &c->send_src[0], n));
-        A(dalloc(c, &c->send_src[1], n));
-        A(dalloc(c, &c->slab_counters, (size_t)4));
+        A(dalloc(c, &c->download_counter, (size_t)4));
         A(dalloc(c, &c->ids_dev, n));
     }
 #undef A
@@ -533,17 +419,28 @@ static int create_common(const SphParams *params, uint32_t capacity, bool slab, 
     return SPH_OK;
 }
 
-int sph_create(const SphParams *params, SphContext **out) { return create_common(params, 0, false, out); }
-
-int sph_slab_create(const SphParams *params, uint32_t local_capacity, SphContext **out)
+int sph_create(const SphParams *params, SphContext **out)
 {
-    if (local_capacity == 0) return fail(nullptr, SPH_E_INVALID_ARG, "local_capacity is 0");
-    return create_common(params, local_capacity, true, out);
+    if (params && params->struct_size == sizeof(SphParams) && params->num_devices >= 2) {
+        if (!out) return fail(nullptr, SPH_E_INVALID_ARG, "out is NULL");
+        *out = nullptr;
+        int rc = validate(nullptr, params);
+        if (rc != SPH_OK) return rc;
+        return group_create(params, out);               // sph_slab_frame.hip: z-slabs on several devices of this process
+    }
+    return create_common(params, 0, false, out);
+}
+
+extern "C++" {
+int slab_context_create(const SphParams *params, uint32_t capacity, SphContext **out) { return create_common(params, capacity, true, out); }
+void derive_params(const SphParams &p, SphDerived *d) { derive(p, d); }
+int validate_params(SphContext *ctx, const SphParams *p) { return validate(ctx, p); }
 }
 
 int sph_destroy(SphContext *c)
 {
     if (!c) return SPH_OK;
+    if (c->is_group) return group_destroy(c);
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     fold_events(c);
@@ -557,6 +454,8 @@ int sph_destroy(SphContext *c)
         (void)hipMemAddressFree(c->mesh_va, c->mesh_va_size);
         (void)hipMemRelease(c->mesh_handle);
     }
+    if (c->owns_group && c->group) slab_group_destroy(c->group);
+    slab_rank_destroy(c);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return SPH_OK;
@@ -565,6 +464,7 @@ int sph_destroy(SphContext *c)
 int sph_upload(SphContext *c, const float *pos4, const float *vel4)
 {
     if (!c) return fail(nullptr, SPH_E_INVALID_ARG, "ctx is NULL");
+    if (c->is_group) return group_upload(c, pos4, vel4);
     if (c->slab) return fail(c, SPH_E_BAD_STATE, "slab context: use sph_slab_upload");
     if (!pos4) return fail(c, SPH_E_INVALID_ARG, "pos4 is NULL");
     HIP_TRY(c, hipSetDevice(c->device));
@@ -589,6 +489,7 @@ int sph_upload(SphContext *c, const float *pos4, const float *vel4)
 int sph_init_particles(SphContext *c, int preset)
 {
     if (!c) return fail(nullptr, SPH_E_INVALID_ARG, "ctx is NULL");
+    if (c->is_group) return fail(c, SPH_E_UNSUPPORTED, "sph_init_particles: not available on a multi-device context");
     if (c->slab) return fail(c, SPH_E_BAD_STATE, "slab context: initialise on the host and use sph_slab_upload");
     if (preset < 0 || preset > 2) return fail(c, SPH_E_INVALID_ARG, "preset %d not in [0,2] (SphFluidSimulation.cs:35)", preset);
     HIP_TRY(c, hipSetDevice(c->device));
@@ -616,6 +517,7 @@ int sph_init_particles(SphContext *c, int preset)
 int sph_download(SphContext *c, float *pos4, float *vel4, float *rho)
 {
     if (!c) return fail(nullptr, SPH_E_INVALID_ARG, "ctx is NULL");
+    if (c->is_group) return group_download(c, pos4, vel4, rho);
     if (c->slab) return fail(c, SPH_E_BAD_STATE, "slab context: use sph_slab_download");
     if (!c->uploaded) return fail(c, SPH_E_BAD_STATE, "sph_download before sph_upload");
     HIP_TRY(c, hipSetDevice(c->device));
@@ -633,6 +535,7 @@ int sph_download(SphContext *c, float *pos4, float *vel4, float *rho)
 int sph_update_mesh_properties(SphContext *c, const SphMeshParams *m)
 {
     if (!c) return fail(nullptr, SPH_E_INVALID_ARG, "ctx is NULL");
+    if (c->is_group) return fail(c, SPH_E_UNSUPPORTED, "sph_update_mesh_properties: not available on a multi-device context");
     if (!m || m->struct_size != sizeof(SphMeshParams))
         return fail(c, SPH_E_INVALID_ARG, "SphMeshParams NULL or struct_size != %zu", sizeof(SphMeshParams));
     if (c->slab) return fail(c, SPH_E_BAD_STATE, "slab context: render feed is built from sph_slab_download output");
@@ -672,6 +575,7 @@ int sph_mesh_properties_device_ptr(SphContext *c, void **dptr, size_t *bytes)
 int sph_export_mesh_properties_fd(SphContext *c, int *fd, size_t *bytes)
 {
     if (!c) return fail(nullptr, SPH_E_INVALID_ARG, "ctx is NULL");
+    if (c->is_group) return fail(c, SPH_E_UNSUPPORTED, "sph_export_mesh_properties_fd: not available on a multi-device context");
     if (!fd) return fail(c, SPH_E_INVALID_ARG, "fd is NULL");
     if (c->slab) return fail(c, SPH_E_BAD_STATE, "slab context: no render feed");
     HIP_TRY(c, hipSetDevice(c->device));
@@ -727,6 +631,7 @@ int sph_export_mesh_properties_fd(SphContext *c, int *fd, size_t *bytes)
 int sph_bucket_generation(SphContext *c)
 {
     if (!c) return fail(nullptr, SPH_E_INVALID_ARG, "ctx is NULL");
+    if (c->is_group) return fail(c, SPH_E_UNSUPPORTED, "sph_bucket_generation: not available on a multi-device context");
     HIP_TRY(c, hipSetDevice(c->device));
     return do_bucket_generation(c);
 }
@@ -734,6 +639,7 @@ int sph_bucket_generation(SphContext *c)
 int sph_density_calculation(SphContext *c)
 {
     if (!c) return fail(nullptr, SPH_E_INVALID_ARG, "ctx is NULL");
+    if (c->is_group) return fail(c, SPH_E_UNSUPPORTED, "sph_density_calculation: not available on a multi-device context");
     HIP_TRY(c, hipSetDevice(c->device));
     return do_density(c);
 }
@@ -741,6 +647,7 @@ int sph_density_calculation(SphContext *c)
 int sph_update_velocity_and_position(SphContext *c, float dt)
 {
     if (!c) return fail(nullptr, SPH_E_INVALID_ARG, "ctx is NULL");
+    if (c->is_group) return fail(c, SPH_E_UNSUPPORTED, "sph_update_velocity_and_position: not available on a multi-device context");
     HIP_TRY(c, hipSetDevice(c->device));
     c->dev.dt_ptr = nullptr;          // dt travels by value here (a replayed frame graph reads it from device memory)
     return do_velpos(c, dt);
@@ -824,6 +731,7 @@ static void account_replayed_frame(SphContext *c, const SphContext::FrameGraph &
 int sph_step(SphContext *c, float delta_time)
 {
     if (!c) return fail(nullptr, SPH_E_INVALID_ARG, "ctx is NULL");
+    if (c->is_group) return group_step(c, delta_time);
     if (c->slab) return fail(c, SPH_E_BAD_STATE, "slab context: the host drives the passes and the halo exchange");
     HIP_TRY(c, hipSetDevice(c->device));
     const float dt = delta_time / c->params.dt_divisor;                 // :102 Time.deltaTime / 25
@@ -908,8 +816,13 @@ int sph_set_params(SphContext *c, const SphParams *p)
                     "num_particles / bucket_resolution / dam_fill_rate / device_id are fixed at sph_create");
     if (p->gas_constant != c->params.gas_constant || p->rest_density != c->params.rest_density)
         c->dev.force_slow = 1;  // pressures change without a density pass: flag is stale until the next one
+    if (p->num_devices != c->params.num_devices || p->halo_planes != c->params.halo_planes)
+        return fail(c, SPH_E_INVALID_ARG, "num_devices / halo_planes are fixed at sph_create");
+    if (c->is_group) return group_set_params(c, p);
     c->params = *p;
     c->profile = (p->flags & SPH_FLAG_PROFILE) != 0;
+    // per-pass events cannot be recorded inside a captured frame: a context that profiles issues its launches directly
+    c->graphs_enabled = !c->slab && !c->profile && !(p->flags & SPH_FLAG_NO_GRAPHS);
     refresh_scalars(c);
     return SPH_OK;
 }
@@ -924,6 +837,7 @@ int sph_get_derived(SphContext *c, SphDerived *out)
 int sph_synchronize(SphContext *c)
 {
     if (!c) return fail(nullptr, SPH_E_INVALID_ARG, "ctx is NULL");
+    if (c->is_group) return group_synchronize(c);
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return SPH_OK;
@@ -932,6 +846,17 @@ int sph_synchronize(SphContext *c)
 int sph_get_stats(SphContext *c, SphStats *out)
 {
     if (!c || !out) return fail(c, SPH_E_INVALID_ARG, "NULL argument");
+    if (c->is_group) return group_get_stats(c, out);
+    if (c->slab && c->group) {
+        int rc = slab_group_finish(c->group);            // (collective in z-slab mode, see include/sph_hip.h)
+        if (rc != SPH_OK) return rc;
+    }
+    return engine_get_stats(c, out);
+}
+}  // extern "C"
+
+int engine_get_stats(SphContext *c, SphStats *out)
+{
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     fold_events(c);
@@ -965,12 +890,19 @@ int sph_get_stats(SphContext *c, SphStats *out)
     out->listed_target_substeps = stat[kStatListed];
     out->scanned_brick_substeps = cnt[kCntActiveBricks];
     out->list_entries = stat[kStatListEntries];
+    out->host_syncs = c->host_syncs;
+    out->frames_rerun = c->group ? slab_group_reruns(c->group) : 0;
+    out->halo_planes = c->slab ? (uint64_t)c->halo_w : 0;
     return SPH_OK;
 }
+
+extern "C" {
 
 int sph_reset_stats(SphContext *c)
 {
     if (!c) return fail(nullptr, SPH_E_INVALID_ARG, "ctx is NULL");
+    if (c->is_group) return group_reset_stats(c);
+    c->host_syncs = 0;
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     fold_events(c);
@@ -988,6 +920,7 @@ int sph_reset_stats(SphContext *c)
 int sph_set_stream(SphContext *c, void *hip_stream)
 {
     if (!c) return fail(nullptr, SPH_E_INVALID_ARG, "ctx is NULL");
+    if (c->is_group) return fail(c, SPH_E_UNSUPPORTED, "sph_set_stream: not available on a multi-device context");
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     fold_events(c);
@@ -1001,186 +934,6 @@ const char *sph_last_error(SphContext *c)
 {
     if (c) return c->last_error.c_str();
     return g_last_error.c_str();
-}
-
-
-// ---- z-slab (multi-GPU) entry points: see include/sph_hip.h ----------------------------------------
-
-#define SLAB_CHECK(c)                                                                   \
-    if (!c) return fail(nullptr, SPH_E_INVALID_ARG, "ctx is NULL");                     \
-    if (!c->slab) return fail(c, SPH_E_BAD_STATE, "not a slab context (sph_slab_create)"); \
-    HIP_TRY(c, hipSetDevice(c->device))
-
-int sph_slab_configure(SphContext *c, int z_lo, int z_hi, int halo_w, int has_left, int has_right)
-{
-    SLAB_CHECK(c);
-    const int R = (int)c->dev.R;
-    if (z_lo < 0 || z_hi > R || z_lo >= z_hi || halo_w < 2)
-        return fail(c, SPH_E_INVALID_ARG, "bad slab range [%d,%d) of %d planes or halo %d < 2", z_lo, z_hi, R, halo_w);
-    c->z_lo = z_lo;
-    c->z_hi = z_hi;
-    c->halo_w = halo_w;
-    c->has_left = has_left != 0;
-    c->has_right = has_right != 0;
-    // an owned target may sit halo_w-1 planes outside the slab and still find its 27 cells in the halo
-    c->dev.zt_lo = c->has_left ? z_lo - (halo_w - 1) : INT_MIN;
-    c->dev.zt_hi = c->has_right ? z_hi - 1 + (halo_w - 1) : INT_MAX;
-    c->dev.zo_lo = z_lo;   // bricks made only of ghost planes have no targets and return at once
-    c->dev.zo_hi = z_hi;
-    return SPH_OK;
-}
-
-int sph_slab_upload(SphContext *c, uint32_t n, const float *pos4, const float *vel4, const uint32_t *ids)
-{
-    SLAB_CHECK(c);
-    if (n > c->capacity) return fail(c, SPH_E_INVALID_ARG, "%u particles exceed the local capacity %u", n, c->capacity);
-    if (n && (!pos4 || !ids)) return fail(c, SPH_E_INVALID_ARG, "pos4 / ids is NULL");
-    HIP_TRY(c, hipMemcpyAsync(c->pos4_dev, pos4, (size_t)n * sizeof(float4), hipMemcpyHostToDevice, c->stream));
-    if (vel4) HIP_TRY(c, hipMemcpyAsync(c->vel4_dev, vel4, (size_t)n * sizeof(float4), hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(c->ids_dev, ids, (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipMemsetAsync(c->dev.counters + kCntWildP, 0, sizeof(unsigned long long) * 3, c->stream));
-    c->dev.wild_v_cur = 0;
-    c->dev.force_slow = 0;
-    c->dev.count = n;
-    c->dev.n_owned = n;
-    launch_slab_upload(c->dev, n, c->pos4_dev, vel4 ? c->vel4_dev : nullptr, c->ids_dev, c->stream);
-    HIP_TRY(c, hipGetLastError());
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    c->uploaded = true;
-    c->grid_valid = false;
-    c->mesh_valid = false;
-    c->substeps_since_upload = 0;
-    c->frames_since_upload = 0;
-    reset_list_policy(c);
-    c->n_ghost[0] = c->n_ghost[1] = c->n_export[0] = c->n_export[1] = 0;
-    return SPH_OK;
-}
-
-int sph_slab_begin_frame(SphContext *c, void *send_left, void *send_right, uint32_t cap_records, uint32_t counts[3])
-{
-    SLAB_CHECK(c);
-    if (!c->uploaded) return fail(c, SPH_E_BAD_STATE, "sph_slab_begin_frame before sph_slab_upload");
-    if (!counts) return fail(c, SPH_E_INVALID_ARG, "counts is NULL");
-    HIP_TRY(c, hipMemsetAsync(c->slab_counters, 0, 4 * sizeof(uint32_t), c->stream));
-    launch_slab_classify(c->dev, c->z_lo, c->z_hi, c->has_left, c->has_right, (float *)send_left, (float *)send_right,
-                         cap_records, c->slab_counters, c->stream);
-    HIP_TRY(c, hipGetLastError());
-    uint32_t h[4];
-    HIP_TRY(c, hipMemcpyAsync(h, c->slab_counters, sizeof h, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    if (h[1] > cap_records || h[2] > cap_records)
-        return fail(c, SPH_E_INVALID_ARG, "migration buffers too small: %u / %u records, capacity %u", h[1], h[2], cap_records);
-    std::swap(c->dev.cur, c->dev.nxt);
-    std::swap(c->dev.id, c->dev.id_nxt);
-    c->dev.count = h[0];
-    c->dev.n_owned = h[0];
-    c->grid_valid = false;
-    c->n_ghost[0] = c->n_ghost[1] = c->n_export[0] = c->n_export[1] = 0;
-    counts[0] = h[0];
-    counts[1] = h[1];
-    counts[2] = h[2];
-    return SPH_OK;
-}
-
-int sph_slab_append(SphContext *c, const void *recv_left, uint32_t n_left, const void *recv_right, uint32_t n_right,
-                    int as_ghost)
-{
-    SLAB_CHECK(c);
-    if ((uint64_t)c->dev.count + n_left + n_right > c->capacity)
-        return fail(c, SPH_E_OOM, "slab overflow: %u + %u + %u particles exceed the local capacity %u", c->dev.count,
-                    n_left, n_right, c->capacity);
-    if (!as_ghost && c->dev.count != c->dev.n_owned)
-        return fail(c, SPH_E_BAD_STATE, "owned particles must be appended before ghosts");
-    launch_slab_append(c->dev, (const float *)recv_left, n_left, c->dev.count, c->stream);
-    launch_slab_append(c->dev, (const float *)recv_right, n_right, c->dev.count + n_left, c->stream);
-    HIP_TRY(c, hipGetLastError());
-    c->dev.count += n_left + n_right;
-    if (as_ghost) {
-        c->n_ghost[0] = n_left;
-        c->n_ghost[1] = n_right;
-    } else {
-        c->dev.n_owned = c->dev.count;
-    }
-    return SPH_OK;
-}
-
-int sph_slab_export_ghosts(SphContext *c, void *send_left, void *send_right, uint32_t cap_records, uint32_t counts[2])
-{
-    SLAB_CHECK(c);
-    if (!counts) return fail(c, SPH_E_INVALID_ARG, "counts is NULL");
-    if (c->dev.count != c->dev.n_owned) return fail(c, SPH_E_BAD_STATE, "export ghosts before appending any");
-    HIP_TRY(c, hipMemsetAsync(c->slab_counters, 0, 4 * sizeof(uint32_t), c->stream));
-    const uint32_t cap = cap_records < c->capacity ? cap_records : c->capacity;
-    launch_slab_export(c->dev, c->z_lo, c->z_hi, c->halo_w, c->has_left, c->has_right, (float *)send_left,
-                       (float *)send_right, c->send_src[0], c->send_src[1], cap, c->slab_counters, c->stream);
-    HIP_TRY(c, hipGetLastError());
-    uint32_t h[4];
-    HIP_TRY(c, hipMemcpyAsync(h, c->slab_counters, sizeof h, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    if (h[1] > cap || h[2] > cap)
-        return fail(c, SPH_E_INVALID_ARG, "ghost buffers too small: %u / %u records, capacity %u", h[1], h[2], cap);
-    c->n_export[0] = counts[0] = h[1];
-    c->n_export[1] = counts[1] = h[2];
-    return SPH_OK;
-}
-
-int sph_slab_pack_update(SphContext *c, int what, void *send_left, void *send_right)
-{
-    SLAB_CHECK(c);
-    if (!c->grid_valid) return fail(c, SPH_E_BAD_STATE, "ghost update before BucketGeneration");
-    if (what != SPH_SLAB_UPDATE_RHO && what != SPH_SLAB_UPDATE_POSVEL) return fail(c, SPH_E_INVALID_ARG, "bad update kind");
-    launch_slab_pack_update(c->dev, c->send_src[0], c->n_export[0], what, (float *)send_left, c->stream);
-    launch_slab_pack_update(c->dev, c->send_src[1], c->n_export[1], what, (float *)send_right, c->stream);
-    HIP_TRY(c, hipGetLastError());
-    return SPH_OK;
-}
-
-int sph_slab_unpack_update(SphContext *c, int what, const void *recv_left, const void *recv_right)
-{
-    SLAB_CHECK(c);
-    if (!c->grid_valid) return fail(c, SPH_E_BAD_STATE, "ghost update before BucketGeneration");
-    if (what != SPH_SLAB_UPDATE_RHO && what != SPH_SLAB_UPDATE_POSVEL) return fail(c, SPH_E_INVALID_ARG, "bad update kind");
-    launch_slab_unpack_update(c->dev, c->dev.n_owned, c->n_ghost[0], what, (const float *)recv_left, c->stream);
-    launch_slab_unpack_update(c->dev, c->dev.n_owned + c->n_ghost[0], c->n_ghost[1], what, (const float *)recv_right,
-                              c->stream);
-    HIP_TRY(c, hipGetLastError());
-    return SPH_OK;
-}
-
-int sph_slab_counts(SphContext *c, uint32_t out[5])
-{
-    SLAB_CHECK(c);
-    if (!out) return fail(c, SPH_E_INVALID_ARG, "out is NULL");
-    out[0] = c->dev.n_owned;
-    out[1] = c->n_ghost[0];
-    out[2] = c->n_ghost[1];
-    out[3] = c->n_export[0];
-    out[4] = c->n_export[1];
-    return SPH_OK;
-}
-
-int sph_slab_download(SphContext *c, uint32_t cap, uint32_t *ids, float *pos4, float *vel4, float *rho, uint32_t *n_out)
-{
-    SLAB_CHECK(c);
-    if (!ids || !pos4 || !vel4 || !rho || !n_out) return fail(c, SPH_E_INVALID_ARG, "NULL argument");
-    if (!c->grid_valid) {   // before the first build: owned particles are the first n_owned entries, no ghosts
-        HIP_TRY(c, hipMemsetAsync(c->dev.ghost, 0, c->capacity, c->stream));
-    }
-    HIP_TRY(c, hipMemsetAsync(c->slab_counters, 0, 4 * sizeof(uint32_t), c->stream));
-    launch_slab_download(c->dev, c->substeps_since_upload, c->dt_last, c->slab_counters, c->ids_dev, c->pos4_dev,
-                         c->vel4_dev, c->rho_id_dev, c->stream);
-    HIP_TRY(c, hipGetLastError());
-    uint32_t n = 0;
-    HIP_TRY(c, hipMemcpyAsync(&n, c->slab_counters, sizeof n, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    if (n > cap) return fail(c, SPH_E_INVALID_ARG, "download arrays hold %u particles, %u owned", cap, n);
-    HIP_TRY(c, hipMemcpyAsync(ids, c->ids_dev, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(pos4, c->pos4_dev, (size_t)n * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(vel4, c->vel4_dev, (size_t)n * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(rho, c->rho_id_dev, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    *n_out = n;
-    return SPH_OK;
 }
 
 

@@ -177,14 +177,35 @@ void launch_init_particles(int preset, uint32_t res, float fill, uint32_t ppd, f
 void launch_mesh_properties(const Dev &d, float low, float high, const float *scale3, const float *sim_trs16,
                             float4 *props, hipStream_t s);
 
-// z-slab mode (sph_kernels_slab.hip)
+// sph_kernels_selftest.hip: out[4] = mismatches of the shared quotient, of the doubled-denominator quotient, of the unscaled sqrt, of the window test
+void launch_selftest_arithmetic(uint64_t n, uint64_t seed, unsigned long long *out, hipStream_t s);
+
+// z-slab mode (sph_kernels_slab.hip; protocol in sph_slab_frame.hip)
+constexpr int kSlabRecordWords = 10;             // x y z rho vx vy vz vel.w id tag
+constexpr int kSlabPosVelWords = 7;              // x y z rho vx vy vz
+constexpr uint32_t kSlabMagic = 0x31485053u;     // "SPH1": sanity word of a message header
+enum SlabCounter : int {
+    kSlabKeep = 0,                 // particles that stay (compacted into nxt)
+    kSlabMigL, kSlabMigR,          // migrants packed for the left / right neighbour
+    kSlabKeptL, kSlabKeptR,        // ... of which stay here as ghosts
+    kSlabGhostL, kSlabGhostR,      // keepers exported as ghosts to the left / right neighbour
+    kSlabLost,                     // particles that jumped past a whole neighbour slab
+    kSlabMisplaced,                // received migrants this slab cannot place (outside it, or in the far face's boundary planes)
+    kSlabCounterCount = 16
+};
+struct SlabArgs {
+    int z_lo, z_hi, halo_w;
+    int has_left, has_right;
+    int nb_lo, nb_hi;              // z_lo of the left neighbour's slab, z_hi of the right neighbour's
+    float *send_mig[2], *send_ghost[2], *kept[2];   // [0] left neighbour, [1] right neighbour
+    uint32_t *send_src[2];         // pre-build index of every particle this slab refreshes for that neighbour
+    uint32_t *counters;            // SlabCounter
+    uint32_t cap_records;          // capacity of each of the buffers above
+};
 void launch_slab_upload(const Dev &d, uint32_t n, const float4 *pos4, const float4 *vel4, const uint32_t *ids, hipStream_t s);
-void launch_slab_classify(const Dev &d, int z_lo, int z_hi, int has_left, int has_right, float *send_l, float *send_r,
-                          uint32_t cap_records, uint32_t *counters, hipStream_t s);
-void launch_slab_append(const Dev &d, const float *recv, uint32_t n, uint32_t at, hipStream_t s);
-void launch_slab_export(const Dev &d, int z_lo, int z_hi, int halo_w, int has_left, int has_right, float *send_l,
-                        float *send_r, uint32_t *src_l, uint32_t *src_r, uint32_t cap_records, uint32_t *counters,
-                        hipStream_t s);
+void launch_slab_classify(const Dev &d, const SlabArgs &a, uint32_t *hdr_send, unsigned long long *viol, hipStream_t s);
+void launch_slab_append(const Dev &d, const float *recv, uint32_t n, uint32_t at, uint32_t *send_src, uint32_t own,
+                        uint32_t cap_src, const SlabArgs &a, int from_side, hipStream_t s);
 void launch_slab_pack_update(const Dev &d, const uint32_t *send_src, uint32_t n, int what, float *out, hipStream_t s);
 void launch_slab_unpack_update(const Dev &d, uint32_t src0, uint32_t n, int what, const float *in, hipStream_t s);
 void launch_slab_download(const Dev &d, int substeps_done, float dt_last, uint32_t *counter, uint32_t *ids,

@@ -231,10 +231,12 @@ __device__ __forceinline__ void walk_list_and_integrate(const Dev &d, uint32_t s
             const Cand b0 = gather(w2), b1 = gather(w3);
             w2 = word(e + 4);
             w3 = word(e + 5);
-            pair_force_vals(d, pix - a0.x, piy - a0.y, piz - a0.z, a0.rho, a0.vx, a0.vy, a0.vz, vix, viy, viz, p_i, f,
-                            a0.take);                                            // :86-95
-            pair_force_vals(d, pix - a1.x, piy - a1.y, piz - a1.z, a1.rho, a1.vx, a1.vy, a1.vz, vix, viy, viz, p_i, f,
-                            e + 1 < n && a1.take);
+            // (the list kernels never run in a wild launch: nl_blocked)
+            const PairPre q0 = pair_pre<true>(d, pix - a0.x, piy - a0.y, piz - a0.z, a0.rho, a0.vx, a0.vy, a0.vz, vix, viy, viz,
+                                              p_i, a0.take);                     // :86-95
+            const PairPre q1 = pair_pre<true>(d, pix - a1.x, piy - a1.y, piz - a1.z, a1.rho, a1.vx, a1.vy, a1.vz, vix, viy, viz,
+                                              p_i, e + 1 < n && a1.take);
+            pair_force_two(q0, q1, f);
             a0 = b0;
             a1 = b1;
         }

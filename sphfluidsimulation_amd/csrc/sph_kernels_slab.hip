@@ -1,130 +1,157 @@
-// z-slab domain decomposition (one process per GPU): device side of the per-frame particle
-// migration and of the ghost-plane exchange.  New work -- the reference is single-GPU
-// (SURVEY.md 8e).  A rank owns the grid planes cz in [z_lo, z_hi) by BUCKET ROW (Bucket.compute:26-29)
-// and keeps copies ("ghosts") of the W planes on either side; ghosts are candidates only.
-// Membership is frozen for the frame like the reference's bucket (SphFluidSimulation.cs:98-102), so
-// the ghost sets are fixed per frame and only their pos / vel values are refreshed per sub-step.
+// z-slab domain decomposition (one slab per GPU): device side of the per-frame particle migration and of the
+// ghost-plane exchange.  New work -- the reference is single-GPU.  A slab owns the grid planes
+// cz in [z_lo, z_hi) by BUCKET ROW (Bucket.compute:26-29) and keeps copies ("ghosts") of the W planes on either side;
+// ghosts are candidates only.  Membership is frozen for the frame like the reference's bucket
+// (SphFluidSimulation.cs:98-102), so the ghost sets are fixed per frame and only their values are refreshed.
+// The frame protocol (who sends what, when the host looks) is in sph_slab_frame.hip.
 //
-// Record layouts (fp32 words), written to caller-provided device buffers that the host side
-// moves with torch.distributed (RCCL over xGMI, or gloo in tests):
-//   particle record (migration, ghost export): x y z rho vx vy vz vel.w id     -> 9 words
-//   ghost update, density pass               : rho                             -> 1 word
-//   ghost update, sub-step                   : x y z rho vx vy vz              -> 7 words
+// Record layouts (fp32 words), in device buffers the transport moves (RCCL over xGMI, peer copies, or host staging):
+//   particle record (migrants, ghost export): x y z rho vx vy vz vel.w id tag   -> 10 words
+//        tag (migrants): index in the sender's list of migrants it KEEPS as ghosts, or 0xFFFFFFFF
+//   ghost update, density pass               : rho                              -> 1 word
+//   ghost update, sub-step                   : x y z rho vx vy vz               -> 7 words
 //     (rho rides along: ghost slots are not integrated locally, so the ping-pong partner of a
 //      ghost slot holds nothing until the update lands)
-#include "sph_internal.hpp"
+#include "sph_sweep_common.hpp"
 
 namespace sph {
 
 constexpr int kBlock = 256;
+constexpr uint32_t kNoTag = 0xFFFFFFFFu;
 
-struct SlabArgs {
-    int z_lo, z_hi, halo_w;
-    int has_left, has_right;
-    float *send[2];         // [0] left neighbour, [1] right neighbour
-    uint32_t *send_src[2];  // pre-build index of every exported ghost
-    uint32_t *counters;     // [0] keep [1] to-left [2] to-right [3] lost (jumped past a neighbour / out of grid)
-    uint32_t cap_records;
-};
-
-__device__ __forceinline__ void write_record(float *buf, uint32_t k, const Dev &d, uint32_t p)
+__device__ __forceinline__ void write_record(float *buf, uint32_t k, const Dev &d, uint32_t p, uint32_t tag)
 {
-    float *r = buf + 9ull * k;
+    float *r = buf + (size_t)kSlabRecordWords * k;
     const float4 rv = d.cur.rv[p];
     r[0] = d.cur.x[p]; r[1] = d.cur.y[p]; r[2] = d.cur.z[p];
     r[3] = rv.x; r[4] = rv.y; r[5] = rv.z; r[6] = rv.w;
     r[7] = d.cur.vw[p];
     r[8] = __uint_as_float(d.id[p]);
+    r[9] = __uint_as_float(tag);
 }
 
-// Stream compaction into up to three output lists at once: every thread of the block calls it with the list it
-// appends to (0..2, or -1 for none) and gets its index in that list.  ONE global atomic per list and block: an atomic
-// per particle on a single counter costs ~3 ns each whatever else the kernel does (3 ms per frame at 16.7 M).
-__device__ __forceinline__ uint32_t block_append3(int which, uint32_t *counters, uint32_t *s_cnt /* [6] */)
+// Stream compaction: every thread of the block calls it; the threads with `pred` get consecutive indices of the list
+// behind `counter`.  ONE global atomic per block: an atomic per particle on a single counter costs ~3 ns each whatever
+// else the kernel does (3 ms per frame at 16.7 M).
+__device__ __forceinline__ uint32_t block_append(bool pred, uint32_t *counter, uint32_t *s_cnt /* [2] */)
 {
     const int lane = threadIdx.x & (kWave - 1);
-    if (threadIdx.x < 3) s_cnt[threadIdx.x] = 0;
+    if (threadIdx.x == 0) s_cnt[0] = 0;
     __syncthreads();
-    uint32_t in_block = 0;
-#pragma unroll
-    for (int w = 0; w < 3; w++) {
-        const unsigned long long m = __ballot(which == w);
-        if (m == 0ull) continue;                   // wave-uniform
-        uint32_t wave_off = 0;
-        if (lane == __ffsll((long long)m) - 1) wave_off = atomicAdd(&s_cnt[w], (uint32_t)__popcll(m));
-        wave_off = __shfl(wave_off, __ffsll((long long)m) - 1, kWave);
-        if (which == w) in_block = wave_off + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+    const unsigned long long m = __ballot(pred);
+    uint32_t wave_off = 0;
+    if (m != 0ull) {                                   // wave-uniform
+        const int leader = __ffsll((long long)m) - 1;
+        if (lane == leader) wave_off = atomicAdd(&s_cnt[0], (uint32_t)__popcll(m));
+        wave_off = __shfl(wave_off, leader, kWave);
     }
+    const uint32_t in_block = wave_off + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
     __syncthreads();
-    if (threadIdx.x < 3 && s_cnt[threadIdx.x]) s_cnt[3 + threadIdx.x] = atomicAdd(&counters[threadIdx.x], s_cnt[threadIdx.x]);
+    if (threadIdx.x == 0 && s_cnt[0]) s_cnt[1] = atomicAdd(counter, s_cnt[0]);
     __syncthreads();
-    return which >= 0 ? s_cnt[3 + which] + in_block : 0u;
+    return pred ? s_cnt[1] + in_block : 0u;
 }
 
-// Frame start: drop last frame's ghosts, keep the particles whose bucket row is still in this slab
-// (compacted into nxt), pack the ones that crossed into a neighbour's slab.
+// Frame start, ONE pass over last frame's arrays (ghosts are dropped):
+//   * particles whose bucket row is still in this slab are compacted into nxt ("keepers", index k); those binned in the
+//     W boundary planes of a face are also packed for that neighbour (its ghosts) and remembered in send_src;
+//   * particles whose row crossed into a neighbour's slab are packed as migrants; the ones that landed in the neighbour's
+//     W boundary planes stay here as ghosts (`kept`), so that the neighbour need not send them back: the tag tells it
+//     which entry of the later refresh messages they are.
+// counters: see SlabCounter.
 __global__ void __launch_bounds__(kBlock) k_slab_classify(Dev d, SlabArgs a)
 {
-    __shared__ uint32_t s_cnt[6];
+    __shared__ uint32_t s_cnt[2];
     const uint32_t s = blockIdx.x * kBlock + threadIdx.x;
-    int which = -1;                                // 0 keep, 1 to the left neighbour, 2 to the right one
+    int dest = -1;                                     // 0 keep, 1 to the left neighbour, 2 to the right one
+    int cz = 0;
+    bool in_grid = false;
     if (s < d.count && !d.ghost[s]) {
         const uint32_t key = bucket_key(d, d.cur.x[s], d.cur.y[s], d.cur.z[s]);
-        which = 0;
-        if (key < d.num_cells) {
-            const int cz = (int)(key / (d.R * d.R));
-            if (cz < a.z_lo && a.has_left) which = 1;          // (a particle cannot lie beyond a missing neighbour)
-            else if (cz >= a.z_hi && a.has_right) which = 2;
+        dest = 0;
+        in_grid = key < d.num_cells;
+        if (in_grid) {
+            cz = (int)(key / (d.R * d.R));
+            if (cz < a.z_lo && a.has_left) dest = 1;   // (a particle cannot lie beyond a missing neighbour)
+            else if (cz >= a.z_hi && a.has_right) dest = 2;
         }
     }
-    const uint32_t k = block_append3(which, a.counters, s_cnt);
-    if (which == 0) {
+    // jumped past a whole neighbour slab: nobody would hold it consistently (the host reports it)
+    const bool lost = (dest == 1 && cz < a.nb_lo) || (dest == 2 && cz >= a.nb_hi);
+    if (lost) atomicAdd(&a.counters[kSlabLost], 1u);
+    const uint32_t k = block_append(dest == 0, &a.counters[kSlabKeep], s_cnt);
+    if (dest == 0) {
         d.nxt.x[k] = d.cur.x[s]; d.nxt.y[k] = d.cur.y[s]; d.nxt.z[k] = d.cur.z[s];
         d.nxt.rv[k] = d.cur.rv[s];
         d.nxt.vw[k] = d.cur.vw[s];
         d.id_nxt[k] = d.id[s];
-    } else if (which > 0) {
-        if (k < a.cap_records) write_record(a.send[which - 1], k, d, s);
+    }
+#pragma unroll
+    for (int side = 0; side < 2; side++) {
+        const bool has = side == 0 ? a.has_left != 0 : a.has_right != 0;
+        if (!has) continue;                            // block-uniform
+        // keepers in this face's boundary planes -> the neighbour's ghosts
+        const bool exported = dest == 0 && in_grid && (side == 0 ? cz < a.z_lo + a.halo_w : cz >= a.z_hi - a.halo_w);
+        const uint32_t g = block_append(exported, &a.counters[kSlabGhostL + side], s_cnt);
+        if (exported && g < a.cap_records) {
+            write_record(a.send_ghost[side], g, d, s, kNoTag);
+            a.send_src[side][g] = k;
+        }
+        // migrants to this neighbour; the ones within its W boundary planes stay here as ghosts
+        const bool mig = dest == side + 1;
+        const bool keep_copy = mig && (side == 0 ? cz >= a.z_lo - a.halo_w : cz < a.z_hi + a.halo_w);
+        const uint32_t kc = block_append(keep_copy, &a.counters[kSlabKeptL + side], s_cnt);
+        const uint32_t m = block_append(mig, &a.counters[kSlabMigL + side], s_cnt);
+        if (mig && m < a.cap_records) write_record(a.send_mig[side], m, d, s, keep_copy ? kc : kNoTag);
+        if (keep_copy && kc < a.cap_records) write_record(a.kept[side], kc, d, s, kNoTag);
     }
 }
 
-// Append received particle records behind the first `at` entries of cur.
-__global__ void __launch_bounds__(kBlock) k_slab_append(Dev d, const float *__restrict__ recv, uint32_t n, uint32_t at)
+// Message headers for the two neighbours + this slab's cumulative halo-violation count, after k_slab_classify.
+__global__ void k_slab_headers(Dev d, SlabArgs a, uint32_t *hdr_send, unsigned long long *viol)
+{
+    if (threadIdx.x < 2) {
+        uint32_t *h = hdr_send + 4 * threadIdx.x;
+        h[0] = a.counters[kSlabMigL + threadIdx.x];
+        h[1] = a.counters[kSlabGhostL + threadIdx.x];
+        h[2] = a.counters[kSlabKeptL + threadIdx.x];   // migrants this slab keeps as ghosts: the receiver refreshes them too
+        h[3] = kSlabMagic ^ (uint32_t)a.halo_w;
+    }
+    if (threadIdx.x == 2) *viol = d.counters[kCntHaloViolation];
+}
+
+// Append received particle records behind the first `at` entries of cur.  Migrants (`send_src` given): a record with a
+// tag is kept as a ghost by its sender, so it joins this slab's export list for that side at position own + tag.
+__global__ void __launch_bounds__(kBlock) k_slab_append(Dev d, const float *__restrict__ recv, uint32_t n, uint32_t at,
+                                                        uint32_t *send_src, uint32_t own, uint32_t cap_src,
+                                                        SlabArgs a, int from_side)
 {
     const uint32_t k = blockIdx.x * kBlock + threadIdx.x;
     if (k >= n) return;
-    const float *r = recv + 9ull * k;
+    const float *r = recv + (size_t)kSlabRecordWords * k;
     const uint32_t p = at + k;
     d.cur.x[p] = r[0]; d.cur.y[p] = r[1]; d.cur.z[p] = r[2];
     d.cur.rv[p] = make_float4(r[3], r[4], r[5], r[6]);
     d.cur.vw[p] = r[7];
     d.id[p] = __float_as_uint(r[8]);
-}
-
-// Owned particles binned into the W boundary planes of either face become the neighbour's ghosts.
-__global__ void __launch_bounds__(kBlock) k_slab_export(Dev d, SlabArgs a)
-{
-    __shared__ uint32_t s_cnt[6];
-    const uint32_t p = blockIdx.x * kBlock + threadIdx.x;
-    bool to_left = false, to_right = false;
-    if (p < d.n_owned) {
-        const uint32_t key = bucket_key(d, d.cur.x[p], d.cur.y[p], d.cur.z[p]);
-        if (key < d.num_cells) {
-            const int cz = (int)(key / (d.R * d.R));
-            to_left = a.has_left && cz < a.z_lo + a.halo_w;
-            to_right = a.has_right && cz >= a.z_hi - a.halo_w;
+    // values from another rank: the "wild" flags the local producers would have raised (sph_sweep_common.hpp)
+    if (is_wild(r[4]) || is_wild(r[5]) || is_wild(r[6])) d.counters[kCntWildV0 + d.wild_v_cur] = 1ull;
+    if (send_src) {
+        const uint32_t tag = __float_as_uint(r[9]);
+        if (tag != kNoTag) {
+            if (own + tag < cap_src) send_src[own + tag] = p;
+            else atomicAdd(&a.counters[kSlabMisplaced], 1u);
         }
-    }
-    // (a slab thinner than 2 * halo_w exports a particle to both sides: two passes)
-    const uint32_t kl = block_append3(to_left ? 1 : -1, a.counters, s_cnt);
-    if (to_left && kl < a.cap_records) {
-        write_record(a.send[0], kl, d, p);
-        a.send_src[0][kl] = p;
-    }
-    const uint32_t kr = block_append3(to_right ? 2 : -1, a.counters, s_cnt);
-    if (to_right && kr < a.cap_records) {
-        write_record(a.send[1], kr, d, p);
-        a.send_src[1][kr] = p;
+        // a migrant must land in this slab, and not in the boundary planes of the FAR face (it would have to be
+        // forwarded as a ghost: slabs are at least 2 W planes thick, so only a particle that outran the halo gets there)
+        const uint32_t key = bucket_key(d, r[0], r[1], r[2]);
+        bool bad = key >= d.num_cells;
+        if (!bad) {
+            const int cz = (int)(key / (d.R * d.R));
+            bad = cz < a.z_lo || cz >= a.z_hi ||
+                  (from_side == 0 ? (a.has_right && cz >= a.z_hi - a.halo_w) : (a.has_left && cz < a.z_lo + a.halo_w));
+        }
+        if (bad) atomicAdd(&a.counters[kSlabMisplaced], 1u);
     }
 }
 
@@ -154,22 +181,39 @@ __global__ void __launch_bounds__(kBlock) k_slab_unpack_update(Dev d, uint32_t s
     const uint32_t s = d.slot_of_src[src0 + k];
     if (what == 0) {
         d.cur.rv[s].x = in[k];
+        if (is_wild_density(d, in[k])) d.counters[kCntWildP] = 1ull;    // (as the density pass does for local particles)
     } else {
         const float *r = in + 7ull * k;
         d.cur.x[s] = r[0]; d.cur.y[s] = r[1]; d.cur.z[s] = r[2];
         if (d.cur.p4) d.cur.p4[s] = make_float4(r[0], r[1], r[2], 0.0f);   // the packed copy the list kernel gathers
         d.cur.rv[s] = make_float4(r[3], r[4], r[5], r[6]);
+        if (is_wild(r[4]) || is_wild(r[5]) || is_wild(r[6])) d.counters[kCntWildV0 + d.wild_v_cur] = 1ull;
     }
+}
+
+// Back to the owned particles a frame started from (re-run with a wider halo): no ghosts, unsorted, wild flag re-raised.
+__global__ void __launch_bounds__(kBlock) k_slab_restore(Dev d, uint32_t n, const float *__restrict__ x, const float *__restrict__ y,
+                                                         const float *__restrict__ z, const float4 *__restrict__ rv,
+                                                         const float *__restrict__ vw, const uint32_t *__restrict__ id)
+{
+    const uint32_t p = blockIdx.x * kBlock + threadIdx.x;
+    if (p >= n) return;
+    const float4 v = rv[p];
+    d.cur.x[p] = x[p]; d.cur.y[p] = y[p]; d.cur.z[p] = z[p];
+    d.cur.rv[p] = v;
+    d.cur.vw[p] = vw[p];
+    d.id[p] = id[p];
+    if (is_wild(v.y) || is_wild(v.z) || is_wild(v.w)) d.counters[kCntWildV0 + d.wild_v_cur] = 1ull;
 }
 
 // Owned particles, compacted, in the reference's texture layout (+ ids).
 __global__ void __launch_bounds__(kBlock) k_slab_download(Dev d, int substeps_done, float dt_last, uint32_t *counter,
                                                           uint32_t *ids, float4 *pos4, float4 *vel4, float *rho)
 {
-    __shared__ uint32_t s_cnt[6];
+    __shared__ uint32_t s_cnt[2];
     const uint32_t s = blockIdx.x * kBlock + threadIdx.x;
     const bool mine = s < d.count && !d.ghost[s];
-    const uint32_t k = block_append3(mine ? 0 : -1, counter, s_cnt);
+    const uint32_t k = block_append(mine, counter, s_cnt);
     if (!mine) return;
     const float4 rv = d.cur.rv[s];
     const float vw = d.cur.vw[s];
@@ -202,24 +246,22 @@ __global__ void __launch_bounds__(kBlock) k_slab_upload(Dev d, uint32_t n, const
 static inline uint32_t cdiv(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
 static inline dim3 grid_for(uint32_t n) { return dim3(n ? cdiv(n, kBlock) : 1u); }
 
-void launch_slab_classify(const Dev &d, int z_lo, int z_hi, int has_left, int has_right, float *send_l, float *send_r,
-                          uint32_t cap_records, uint32_t *counters, hipStream_t s)
+void launch_slab_classify(const Dev &d, const SlabArgs &a, uint32_t *hdr_send, unsigned long long *viol, hipStream_t s)
 {
-    SlabArgs a{z_lo, z_hi, 0, has_left, has_right, {send_l, send_r}, {nullptr, nullptr}, counters, cap_records};
     hipLaunchKernelGGL(k_slab_classify, grid_for(d.count), dim3(kBlock), 0, s, d, a);
+    hipLaunchKernelGGL(k_slab_headers, dim3(1), dim3(64), 0, s, d, a, hdr_send, viol);
 }
 
-void launch_slab_append(const Dev &d, const float *recv, uint32_t n, uint32_t at, hipStream_t s)
+void launch_slab_append(const Dev &d, const float *recv, uint32_t n, uint32_t at, uint32_t *send_src, uint32_t own,
+                        uint32_t cap_src, const SlabArgs &a, int from_side, hipStream_t s)
 {
-    if (n) hipLaunchKernelGGL(k_slab_append, grid_for(n), dim3(kBlock), 0, s, d, recv, n, at);
+    if (n) hipLaunchKernelGGL(k_slab_append, grid_for(n), dim3(kBlock), 0, s, d, recv, n, at, send_src, own, cap_src, a, from_side);
 }
 
-void launch_slab_export(const Dev &d, int z_lo, int z_hi, int halo_w, int has_left, int has_right, float *send_l,
-                        float *send_r, uint32_t *src_l, uint32_t *src_r, uint32_t cap_records, uint32_t *counters,
-                        hipStream_t s)
+void launch_slab_restore(const Dev &d, uint32_t n, const float *x, const float *y, const float *z, const float4 *rv, const float *vw,
+                         const uint32_t *id, hipStream_t s)
 {
-    SlabArgs a{z_lo, z_hi, halo_w, has_left, has_right, {send_l, send_r}, {src_l, src_r}, counters, cap_records};
-    hipLaunchKernelGGL(k_slab_export, grid_for(d.n_owned), dim3(kBlock), 0, s, d, a);
+    if (n) hipLaunchKernelGGL(k_slab_restore, grid_for(n), dim3(kBlock), 0, s, d, n, x, y, z, rv, vw, id);
 }
 
 void launch_slab_pack_update(const Dev &d, const uint32_t *send_src, uint32_t n, int what, float *out, hipStream_t s)

@@ -43,7 +43,7 @@ __device__ __forceinline__ uint32_t density_target(const Dev &d, uint32_t s)
             }
     d.cur.rv[s].x = rho;                                                         // :59
     // pressure that a later VelPos pass derives from this density (VelPos.compute:61,87)
-    if (is_wild(d.gas_const * (rho - d.rest_density))) d.counters[kCntWildP] = 1ull;
+    if (is_wild_density(d, rho)) d.counters[kCntWildP] = 1ull;
     return visited;
 }
 
@@ -72,7 +72,7 @@ __device__ __forceinline__ void velpos_target(const Dev &d, uint32_t s, bool liv
                     for (uint32_t k = 0; k < cr.cnt; k++) {
                         const uint32_t j = cr.start + k;
                         if (j == s) continue;                                    // :82 (slot <-> id is 1:1)
-                        pair_force(d, j, pix, piy, piz, vix, viy, viz, p_i, f);
+                        pair_force(d, j, pix, piy, piz, vix, viy, viz, p_i, f, true);
                     }
                 }
     } else {
@@ -104,7 +104,7 @@ __device__ __forceinline__ void velpos_target(const Dev &d, uint32_t s, bool liv
                 const int xo = c / 9 - 1, yo = (c / 3) % 3 - 1, zo = c % 3 - 1;
                 const uint32_t cell = (uint32_t)(ix + xo) + (uint32_t)(iy + yo) * d.R + (uint32_t)(iz + zo) * d.R * d.R;
                 const uint32_t j = d.cell_start[cell] + (ent & 31u);
-                pair_force(d, j, pix, piy, piz, vix, viy, viz, p_i, f);
+                pair_force(d, j, pix, piy, piz, vix, viy, viz, p_i, f, false);
             }
         }
     }

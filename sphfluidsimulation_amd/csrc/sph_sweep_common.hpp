@@ -4,6 +4,7 @@
 // (Density.compute:22-27, VelPos.compute:33-44,86-157) -- see oracle/sph_oracle.c for the contract.
 #pragma once
 
+#include "sph_fastdiv.hpp"
 #include "sph_internal.hpp"
 
 namespace sph {
@@ -11,6 +12,12 @@ namespace sph {
 constexpr float kWildLimit = 1e15f;
 
 __device__ __forceinline__ bool is_wild(float v) { return !(fabsf(v) < kWildLimit); }
+// a density whose pressure k * (rho - rho0) (VelPos.compute:61,87) is wild, or that is itself beyond the denominator window of
+// sph_fastdiv.hpp (the physical bound is ~27 * 32 * m * c / h^3 < 3e7 * dam_fill_rate)
+__device__ __forceinline__ bool is_wild_density(const Dev &d, float rho)
+{
+    return is_wild(d.gas_const * (rho - d.rest_density)) || !(rho < 1e9f);
+}
 
 struct CellRange {
     uint32_t start, cnt;
@@ -48,47 +55,111 @@ struct Force {
     float vx, vy, vz;  // f_vis
 };
 
-// VelPos.compute:86-95 for one listed candidate j != i whose fields are already in registers.
-// `take` = false turns the candidate into a no-op (self / padding).  Written WITHOUT branches: a
-// dependent fp32 instruction issues only every ~8 cycles on gfx950 and the sweeps run at 3 waves per
-// SIMD, so the seven IEEE divisions and the sqrt must be independent straight-line chains the
-// scheduler can interleave.  The reference's guards become selects of an exact 0.0f; adding +0.0f
-// to an accumulator that is never -0 is the same as not adding (see sph_kernels_sweep.hip).
-__device__ __forceinline__ void pair_force_vals(const Dev &d, float rx, float ry, float rz, float rho_j,
-                                                float vjx, float vjy, float vjz, float vix, float viy,
-                                                float viz, float p_i, Force &f, bool take = true)
+// VelPos.compute:86-95 for one listed candidate j != i whose fields are already in registers, in three steps so that
+// callers can run TWO candidates through each step together (their sqrt / division chains interleave: a dependent fp32
+// instruction issues only every ~8 cycles on gfx950):
+//   pair_pre     everything up to the seven divisions (the numerators and the two denominators |r| and rho_j);
+//   pair_min_key smallest magnitude among the nonzero numerators, as a bit key: below kMagKeyMin the shared-reciprocal
+//                quotients of sph_fastdiv.hpp are not guaranteed to equal `/` and the WAVE takes the plain divisions;
+//   pair_finish  the divisions (SHARED: one refined reciprocal per denominator; else the compiler's `/`) and the sums.
+// `take` = false turns the candidate into a no-op (self / padding).  Written WITHOUT branches inside a step; the
+// reference's guards become selects of an exact 0.0f, and adding +0.0f to an accumulator that is never -0 is the same
+// as not adding (see sph_kernels_sweep.hpp).  FAST = false (wild launches: some |v|, |p| >= 1e15, rho >= 1e9, inf or
+// NaN) evaluates sqrtf and `/` literally.
+struct PairPre {
+    float abs_r, rho_j, gv;
+    float ngx, ngy, ngz;   // sc * r_ij          :37
+    float ncp;             // p_i + p_j          :93
+    float nvx, nvy, nvz;   // v_j - v_i          :94
+    bool in_p, ok;
+};
+
+template <bool FAST>
+__device__ __forceinline__ PairPre pair_pre(const Dev &d, float rx, float ry, float rz, float rho_j, float vjx, float vjy,
+                                            float vjz, float vix, float viy, float viz, float p_i, bool take)
 {
     const float epsilon = 1e-6f;                                                 // :5
     const float h = d.h;
+    PairPre q;
     const float p_j = d.gas_const * (rho_j - d.rest_density);                    // :87
-    const bool ok = take && (rho_j > epsilon);                                   // :91
-    const float abs_r = sqrtf((rx * rx + ry * ry) + rz * rz);                    // :35, :42
-    const float diff_r = h - abs_r;                                              // :36
-    const bool in_p = (epsilon < diff_r) && (epsilon < abs_r);                   // :37
+    q.ok = take && (rho_j > epsilon);                                            // :91
+    const float r2 = (rx * rx + ry * ry) + rz * rz;
+    q.abs_r = FAST ? sqrt_unscaled(r2) : sqrtf(r2);                              // :35, :42
+    const float diff_r = h - q.abs_r;                                            // :36
+    q.in_p = (epsilon < diff_r) && (epsilon < q.abs_r);                          // :37
     const float sc = d.c_over_h6 * ((diff_r * diff_r) * diff_r);
-    const float gpx = in_p ? (sc * rx) / abs_r : 0.0f;
-    const float gpy = in_p ? (sc * ry) / abs_r : 0.0f;
-    const float gpz = in_p ? (sc * rz) / abs_r : 0.0f;
-    const float cp = (p_i + p_j) / (2.0f * rho_j);                               // :93
-    const float gv = abs_r < h ? d.c_over_h6 * (h - abs_r) : 0.0f;               // :43
+    q.ngx = sc * rx; q.ngy = sc * ry; q.ngz = sc * rz;
+    q.ncp = p_i + p_j;                                                           // :93
+    q.gv = q.abs_r < h ? d.c_over_h6 * (h - q.abs_r) : 0.0f;                     // :43
+    q.nvx = vjx - vix; q.nvy = vjy - viy; q.nvz = vjz - viz;                     // :94
+    q.rho_j = rho_j;
+    return q;
+}
+
+__device__ __forceinline__ uint32_t pair_min_key(const PairPre &q)
+{
+    return umin3(umin3(mag_key(q.ngx), mag_key(q.ngy), mag_key(q.ngz)), umin3(mag_key(q.nvx), mag_key(q.nvy), mag_key(q.nvz)),
+                 mag_key(q.ncp));
+}
+
+template <bool SHARED>
+__device__ __forceinline__ void pair_finish(const PairPre &q, Force &f)
+{
+    float gpx, gpy, gpz, cp, qx, qy, qz;
+    if (SHARED) {
+        const Recip ra = recip_refined(q.abs_r), rr = recip_refined(q.rho_j), r2 = recip_twice(rr);
+        gpx = div_shared(q.ngx, ra); gpy = div_shared(q.ngy, ra); gpz = div_shared(q.ngz, ra);
+        cp = div_shared(q.ncp, r2);
+        qx = div_shared(q.nvx, rr); qy = div_shared(q.nvy, rr); qz = div_shared(q.nvz, rr);
+    } else {
+        gpx = q.ngx / q.abs_r; gpy = q.ngy / q.abs_r; gpz = q.ngz / q.abs_r;     // :37
+        cp = q.ncp / (2.0f * q.rho_j);                                           // :93
+        qx = q.nvx / q.rho_j; qy = q.nvy / q.rho_j; qz = q.nvz / q.rho_j;        // :94
+    }
+    gpx = q.in_p ? gpx : 0.0f; gpy = q.in_p ? gpy : 0.0f; gpz = q.in_p ? gpz : 0.0f;
     const float tx = cp * gpx, ty = cp * gpy, tz = cp * gpz;
-    const float ux = ((vjx - vix) / rho_j) * gv;                                 // :94
-    const float uy = ((vjy - viy) / rho_j) * gv;
-    const float uz = ((vjz - viz) / rho_j) * gv;
-    f.px += ok ? tx : 0.0f;
-    f.py += ok ? ty : 0.0f;
-    f.pz += ok ? tz : 0.0f;
-    f.vx += ok ? ux : 0.0f;
-    f.vy += ok ? uy : 0.0f;
-    f.vz += ok ? uz : 0.0f;
+    const float ux = qx * q.gv, uy = qy * q.gv, uz = qz * q.gv;
+    f.px += q.ok ? tx : 0.0f;
+    f.py += q.ok ? ty : 0.0f;
+    f.pz += q.ok ? tz : 0.0f;
+    f.vx += q.ok ? ux : 0.0f;
+    f.vy += q.ok ? uy : 0.0f;
+    f.vz += q.ok ? uz : 0.0f;
+}
+
+// Two candidates (a then b: the reference's order) of a launch that is not "wild".
+__device__ __forceinline__ void pair_force_two(const PairPre &a, const PairPre &b, Force &f)
+{
+    const uint32_t ka = pair_min_key(a), kb = pair_min_key(b);
+    if (__builtin_expect(__any((ka < kb ? ka : kb) < kMagKeyMin), 0)) {          // wave-uniform; practically never
+        pair_finish<false>(a, f);
+        pair_finish<false>(b, f);
+    } else {
+        pair_finish<true>(a, f);
+        pair_finish<true>(b, f);
+    }
+}
+
+// One candidate; `literal` = the launch is wild (wave-uniform).
+__device__ __forceinline__ void pair_force_vals(const Dev &d, float rx, float ry, float rz, float rho_j,
+                                                float vjx, float vjy, float vjz, float vix, float viy,
+                                                float viz, float p_i, Force &f, bool take, bool literal)
+{
+    if (literal) {
+        pair_finish<false>(pair_pre<false>(d, rx, ry, rz, rho_j, vjx, vjy, vjz, vix, viy, viz, p_i, take), f);
+        return;
+    }
+    const PairPre q = pair_pre<true>(d, rx, ry, rz, rho_j, vjx, vjy, vjz, vix, viy, viz, p_i, take);
+    if (__builtin_expect(__any(pair_min_key(q) < kMagKeyMin), 0)) pair_finish<false>(q, f);
+    else pair_finish<true>(q, f);
 }
 
 __device__ __forceinline__ void pair_force(const Dev &d, uint32_t j, float pix, float piy, float piz,
-                                           float vix, float viy, float viz, float p_i, Force &f)
+                                           float vix, float viy, float viz, float p_i, Force &f, bool literal)
 {
     const float4 rv = d.cur.rv[j];
     pair_force_vals(d, pix - d.cur.x[j], piy - d.cur.y[j], piz - d.cur.z[j], rv.x, rv.y, rv.z, rv.w, vix, viy,
-                    viz, p_i, f);                                                // :86-89
+                    viz, p_i, f, true, literal);                                 // :86-89
 }
 
 struct Pos3 {

@@ -1,24 +1,21 @@
-"""z-slab domain decomposition of the SPH frame update: one process per GPU, torch.distributed
-(backend "nccl" = RCCL over xGMI on MI355X; "gloo" in tests) for the neighbour exchange.
+"""z-slab domain decomposition of the SPH frame update, one process per GPU.
 
 New work -- the reference is single-GPU.  The particle set is split along z,
 the slowest axis of the bucket row index ``cx + cy*R + cz*R^2`` (Assets/Resources/Bucket.compute:28):
-rank r owns the grid planes ``cz in [z_lo, z_hi)`` BY BUCKET ROW and holds ghost copies of
-``halo_w`` planes on either side.  The reference freezes bucket and density for the 5 sub-steps of
-a frame (Assets/Scripts/SphFluidSimulation.cs:98-102), so per frame there is
+rank r owns the grid planes ``cz in [z_lo, z_hi)`` BY BUCKET ROW and holds ghost copies of the halo
+planes on either side.  The frame itself -- classify / pack, the exchange with the two z-neighbours,
+BucketGeneration, DensityCalculation, the ghost refreshes between the sub-steps, the re-run with a
+wider halo when a particle outran it -- happens INSIDE libsph_hip.so (``sph_slab_step``,
+csrc/sph_slab_frame.hip).  This module only
 
-    1 migration exchange  (particles whose bucket row left the slab; variable size)
-    1 ghost export        (boundary planes, full state; variable size)
-    1 ghost rho refresh   (after the density pass; fixed size)
-    S-1 ghost pos/vel refreshes (after every sub-step but the last; fixed size)
+  * decides the initial ownership (host side, numpy: the same arithmetic as Bucket.compute:26-29),
+  * gives the library its transport: RCCL (``ncclSend/ncclRecv`` over xGMI from inside the library;
+    the 128-byte communicator id travels through torch.distributed) or, for rehearsals with several
+    ranks on ONE GPU, a host transport: the library stages its messages through pinned memory and
+    calls back into ``HostExchange``, which moves them with torch.distributed (gloo),
+  * gathers results by particle id.
 
-all point-to-point with the two z-neighbours (no bulk collective: xGMI is point-to-point and a
-rank only ever needs its two faces).  With ``halo_w = 2`` an owned particle may drift one plane
-out of its slab inside a frame and still find all 27 cells; ``stats()['halo_violations']`` counts
-targets that went further (the result is then no longer identical to the single-GPU run).
-
-The device work is libsph_hip.so's ``sph_slab_*`` entry points (include/sph_hip.h); this module only
-sequences them and moves their buffers.
+``torch.distributed`` is the control plane (rendezvous, id broadcast, barriers, timing reductions).
 """
 from __future__ import annotations
 
@@ -30,13 +27,11 @@ import numpy as np
 from . import _native as N
 from . import presets
 
-RECORD = N.SPH_SLAB_RECORD_WORDS
-
 
 # ---- partition (host side, numpy) -----------------------------------------------------------------
 
 def slab_planes(R: int, world: int):
-    """[z_lo, z_hi) per rank: R grid planes split as evenly as possible."""
+    """[z_lo, z_hi) per rank: R grid planes split as evenly as possible (= sph_slab_planes)."""
     return [((r * R) // world, ((r + 1) * R) // world) for r in range(world)]
 
 
@@ -67,14 +62,11 @@ def owner_of_plane(cz: np.ndarray, R: int, world: int) -> np.ndarray:
     return np.where(cz < 0, 0, np.searchsorted(bounds, cz, side="right"))
 
 
-# ---- neighbour transport --------------------------------------------------------------------------
+# ---- host transport: what the library calls back into (rehearsal: several ranks on one GPU, gloo) -------------
 
-class NeighbourTransport:
-    """Point-to-point exchange with the left (rank-1) and right (rank+1) z-neighbour.
-
-    Tensors are handed to the process group directly when it can take them (nccl + device tensors,
-    gloo + host tensors) and staged through host memory otherwise (gloo + device tensors: the
-    single-GPU rehearsal used by the tests)."""
+class HostExchange:
+    """Moves the library's HOST-staged messages between z-neighbours with torch.distributed
+    (sph_slab_set_host_transport).  Every rank calls exchange / allreduce in the same order."""
 
     def __init__(self, rank: int, world: int, group=None):
         import torch
@@ -83,80 +75,102 @@ class NeighbourTransport:
         self.rank, self.world, self.group = rank, world, group
         self.left = rank - 1 if rank > 0 else None
         self.right = rank + 1 if rank < world - 1 else None
-        self.backend = dist.get_backend(group) if world > 1 else "none"
+        self.calls = 0
+        # the CFUNCTYPE objects must outlive the context that holds their addresses
+        self.exchange_cb = N.HOST_EXCHANGE_FN(self._exchange)
+        self.allreduce_cb = N.HOST_ALLREDUCE_FN(self._allreduce)
 
-    def _direct(self, t) -> bool:
-        return (self.backend == "nccl") == t.is_cuda
+    def _tensor(self, ptr, nbytes):
+        buf = (C.c_uint8 * nbytes).from_address(ptr)
+        return self.torch.from_numpy(np.ctypeslib.as_array(buf))
 
-    def exchange(self, send_left, send_right, n_recv_left: int, n_recv_right: int, like):
-        """Send 1-D tensors to the neighbours (None / empty = nothing) and receive n_recv_* elements
-        from each; returns (recv_left, recv_right) on ``like``'s device."""
-        torch, dist = self.torch, self.dist
-        recv = [None, None]
-        ops, staged = [], []
-        for side, peer, snd, nrecv in ((0, self.left, send_left, n_recv_left), (1, self.right, send_right, n_recv_right)):
-            if peer is None:
-                continue
-            if snd is not None and snd.numel() > 0:
-                buf = snd.contiguous() if self._direct(snd) else snd.detach().cpu().contiguous()
-                ops.append(dist.P2POp(dist.isend, buf, peer, group=self.group))
-            if nrecv > 0:
-                if self._direct(like):
-                    r = torch.empty(nrecv, dtype=like.dtype, device=like.device)
-                else:
-                    r = torch.empty(nrecv, dtype=like.dtype)
-                    staged.append(side)
-                recv[side] = r
-                ops.append(dist.P2POp(dist.irecv, r, peer, group=self.group))
-        if ops:
-            for req in dist.batch_isend_irecv(ops):
-                req.wait()
-        for side in staged:
-            recv[side] = recv[side].to(like.device)
-        for side in (0, 1):
-            if recv[side] is None:
-                recv[side] = torch.empty(0, dtype=like.dtype, device=like.device)
-        return recv[0], recv[1]
+    def _exchange(self, user, sl, nsl, sr, nsr, rl, nrl, rr, nrr):
+        try:
+            dist = self.dist
+            ops = []
+            for peer, sp, ns, rp, nr in ((self.left, sl, nsl, rl, nrl), (self.right, sr, nsr, rr, nrr)):
+                if peer is None:
+                    if ns or nr:
+                        return 2
+                    continue
+                if ns:
+                    ops.append(dist.P2POp(dist.isend, self._tensor(sp, ns), peer, group=self.group))
+                if nr:
+                    ops.append(dist.P2POp(dist.irecv, self._tensor(rp, nr), peer, group=self.group))
+            if ops:
+                for req in dist.batch_isend_irecv(ops):
+                    req.wait()
+            self.calls += 1
+            return 0
+        except Exception as e:  # never let an exception cross the C boundary
+            print(f"HostExchange rank {self.rank}: {e!r}", flush=True)
+            return 1
 
-    def exchange_counts(self, to_left: int, to_right: int):
-        """Tell each neighbour how many elements it is about to receive; returns (from_left, from_right)."""
-        torch = self.torch
-        dev = "cuda" if self.backend == "nccl" else "cpu"
-        like = torch.empty(0, dtype=torch.int64, device=dev)
-        sl = torch.tensor([to_left], dtype=torch.int64, device=dev) if self.left is not None else None
-        sr = torch.tensor([to_right], dtype=torch.int64, device=dev) if self.right is not None else None
-        rl, rr = self.exchange(sl, sr, 1 if self.left is not None else 0, 1 if self.right is not None else 0, like)
-        return (int(rl[0]) if rl.numel() else 0), (int(rr[0]) if rr.numel() else 0)
+    def _allreduce(self, user, value):
+        try:
+            t = self.torch.tensor([int(value[0])], dtype=self.torch.int64)
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+            value[0] = int(t[0])
+            return 0
+        except Exception as e:
+            print(f"HostExchange rank {self.rank}: {e!r}", flush=True)
+            return 1
+
+
+class Control:
+    """Control-plane reductions over torch.distributed (CPU tensors; world 1 needs no process group)."""
+
+    def __init__(self, rank: int, world: int, group=None):
+        self.rank, self.world, self.group = rank, world, group
 
     def all_reduce(self, value: float, op: str = "max") -> float:
         if self.world == 1:
             return value
-        torch, dist = self.torch, self.dist
-        dev = "cuda" if self.backend == "nccl" else "cpu"
-        t = torch.tensor([value], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op={"max": dist.ReduceOp.MAX, "sum": dist.ReduceOp.SUM}[op], group=self.group)
+        import torch
+        import torch.distributed as dist
+        t = torch.tensor([value], dtype=torch.float64)
+        dist.all_reduce(t, op={"max": dist.ReduceOp.MAX, "sum": dist.ReduceOp.SUM, "min": dist.ReduceOp.MIN}[op], group=self.group)
         return float(t[0])
 
     def barrier(self):
         if self.world > 1:
-            self.dist.barrier(group=self.group)
+            import torch.distributed as dist
+            dist.barrier(group=self.group)
+
+    def broadcast_bytes(self, data: bytes | None, nbytes: int, src: int = 0) -> bytes:
+        if self.world == 1:
+            return data
+        import torch
+        import torch.distributed as dist
+        t = torch.zeros(nbytes, dtype=torch.uint8)
+        if self.rank == src:
+            t.copy_(torch.frombuffer(bytearray(data), dtype=torch.uint8))
+        dist.broadcast(t, src=src, group=self.group)
+        return bytes(t.numpy().tobytes())
 
 
 # ---- the per-rank simulation ------------------------------------------------------------------------
 
 class SlabSimulation:
-    """Same surface as simulation.SphFluidSimulation (Start / Update / download), one z-slab per rank."""
+    """Same surface as simulation.SphFluidSimulation (Start / Update / download), one z-slab per rank.
+
+    transport = "rccl": the library talks to its neighbours itself (one GPU per rank);
+                "host": HostExchange over the default torch.distributed group (gloo; ranks may share a GPU);
+                "auto": rccl, falling back to host on EVERY rank if any rank could not set it up."""
 
     def __init__(self, rank: int, world: int, particleNumber: int, bucketResolution: int, damFillRate: float = 0.5,
                  viscosity: float = 0.01, restDensity: float = 1.5, gasConstant: float = 150.0,
                  stiffnessCoefficient: float = 5000.0, dampingCoefficient: float = 10.0, device_id: int = 0,
-                 halo_w: int = 2, capacity_factor: float = 1.6, profile: bool = False, group=None):
-        import torch
-        self.torch = torch
+                 halo_w: int = 2, capacity_factor: float = 1.6, profile: bool = False, group=None,
+                 transport: str = "auto"):
         self.rank, self.world = rank, world
         self.halo_w = halo_w
         self.capacity_factor = capacity_factor
-        self.transport = NeighbourTransport(rank, world, group)
+        self.control = Control(rank, world, group)
+        self.group = group
+        self.transport_request = transport
+        self.transport = None
+        self.host_exchange = None
         p = N.default_params()
         p.num_particles = int(particleNumber)
         p.bucket_resolution = int(bucketResolution)
@@ -164,89 +178,83 @@ class SlabSimulation:
         p.viscosity, p.rest_density, p.gas_constant = viscosity, restDensity, gasConstant
         p.stiffness_coeff, p.damping_coeff = stiffnessCoefficient, dampingCoefficient
         p.device_id = device_id
+        p.halo_planes = int(halo_w)
         p.flags = N.SPH_FLAG_PROFILE if profile else 0
         self._params = p
         self.R = int(bucketResolution)
         self.z_lo, self.z_hi = slab_planes(self.R, world)[rank]
-        self.device = torch.device("cuda", device_id)
         self._ctx = C.c_void_p()
         self.frames = 0
 
     def _check(self, rc):
         N.check(rc, self._ctx)
 
+    def _setup_transport(self):
+        L = N.lib()
+        want = self.transport_request
+        if self.world == 1:
+            self.transport = "none"
+            return
+        ok = 0.0
+        if want in ("rccl", "auto"):
+            try:
+                ident = C.create_string_buffer(N.SPH_COMM_ID_BYTES)
+                if self.rank == 0:
+                    N.check(L.sph_comm_unique_id(ident))
+                raw = self.control.broadcast_bytes(ident.raw if self.rank == 0 else None, N.SPH_COMM_ID_BYTES)
+                ident = C.create_string_buffer(raw, N.SPH_COMM_ID_BYTES)
+                self._check(L.sph_slab_comm_init(self._ctx, ident))
+                ok = 1.0
+            except N.SphError as e:
+                if want == "rccl":
+                    raise
+                print(f"rank {self.rank}: RCCL transport unavailable ({e}); falling back to the host transport", flush=True)
+            if self.control.all_reduce(ok, "min") >= 1.0:
+                self.transport = "rccl"
+                return
+            if want == "rccl":
+                raise RuntimeError("RCCL transport could not be set up on every rank")
+        self.host_exchange = HostExchange(self.rank, self.world, self.group)
+        self._check(L.sph_slab_set_host_transport(self._ctx, self.host_exchange.exchange_cb, self.host_exchange.allreduce_cb, None))
+        self.transport = "host"
+
     # -- Start(): distribute the initial particle set ---------------------------------------------------
     def Start(self, positions: np.ndarray, velocities: np.ndarray | None = None):
         """Every rank passes the same global float4 arrays (id order) and keeps the particles whose
         bucket row lies in its planes."""
-        torch = self.torch
+        L = N.lib()
         pos = np.ascontiguousarray(positions, np.float32).reshape(-1, 4)
-        owner = owner_of_plane(bucket_plane(pos, self.R), self.R, self.world)
+        cz = bucket_plane(pos, self.R)
+        owner = owner_of_plane(cz, self.R, self.world)
         ids = np.nonzero(owner == self.rank)[0].astype(np.uint32)
         n_global = pos.shape[0]
-        planes = max(self.z_hi - self.z_lo, 1)
-        share = n_global / self.world * (planes + 2 * self.halo_w) / planes
-        self.capacity = int(min(max(share * self.capacity_factor, len(ids) * self.capacity_factor, 4096), n_global + 64))
-        self._check(N.lib().sph_slab_create(C.byref(self._params), self.capacity, C.byref(self._ctx)))
-        self._check(N.lib().sph_slab_configure(self._ctx, self.z_lo, self.z_hi, self.halo_w,
-                                               int(self.rank > 0), int(self.rank < self.world - 1)))
-        torch.cuda.set_device(self.device)
-        self._check(N.lib().sph_set_stream(self._ctx, C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        # capacity: owned + up to 8 ghost planes either side (the halo may grow), with headroom
+        near = np.count_nonzero((cz >= self.z_lo - 8) & (cz < self.z_hi + 8) & (owner != self.rank))
+        self.capacity = int(min(max((len(ids) + near) * self.capacity_factor, 4096), n_global + 64))
+        self._check(L.sph_slab_create(C.byref(self._params), self.capacity, C.byref(self._ctx)))
+        self._check(L.sph_slab_configure(self._ctx, self.rank, self.world))
+        self._setup_transport()
         my_pos = np.ascontiguousarray(pos[ids])
         my_vel = None
         if velocities is not None:
             my_vel = np.ascontiguousarray(np.asarray(velocities, np.float32).reshape(-1, 4)[ids])
         fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float)) if a is not None else None
-        self._check(N.lib().sph_slab_upload(self._ctx, len(ids), fp(my_pos), fp(my_vel),
-                                            ids.ctypes.data_as(C.POINTER(C.c_uint32))))
-        words = self.capacity * RECORD
-        self._send = [torch.empty(words, dtype=torch.float32, device=self.device) for _ in range(2)]
+        self._check(L.sph_slab_upload(self._ctx, len(ids), fp(my_pos), fp(my_vel), ids.ctypes.data_as(C.POINTER(C.c_uint32))))
         self.substeps = int(self._params.substeps)
-        self.dt_divisor = float(self._params.dt_divisor)
         return self
 
-    # -- one Update(): SphFluidSimulation.cs:96-102 with the halo exchange woven in ----------------------
+    # -- one Update(): SphFluidSimulation.cs:96-102, halo exchange included --------------------------------
     def Update(self, deltaTime: float):
-        L, T = N.lib(), self.transport
-        sl, sr = self._send
-        p = lambda t: C.c_void_p(t.data_ptr())
-        # 1. migration
-        c3 = (C.c_uint32 * 3)()
-        self._check(L.sph_slab_begin_frame(self._ctx, p(sl), p(sr), self.capacity, c3))
-        to_l, to_r = int(c3[1]), int(c3[2])
-        in_l, in_r = T.exchange_counts(to_l, to_r)
-        rl, rr = T.exchange(sl[:to_l * RECORD], sr[:to_r * RECORD], in_l * RECORD, in_r * RECORD, sl)
-        self._check(L.sph_slab_append(self._ctx, p(rl), in_l, p(rr), in_r, 0))
-        # 2. ghost planes
-        c2 = (C.c_uint32 * 2)()
-        self._check(L.sph_slab_export_ghosts(self._ctx, p(sl), p(sr), self.capacity, c2))
-        ex_l, ex_r = int(c2[0]), int(c2[1])
-        gh_l, gh_r = T.exchange_counts(ex_l, ex_r)
-        rl, rr = T.exchange(sl[:ex_l * RECORD], sr[:ex_r * RECORD], gh_l * RECORD, gh_r * RECORD, sl)
-        self._check(L.sph_slab_append(self._ctx, p(rl), gh_l, p(rr), gh_r, 1))
-        # 3. BucketGeneration + DensityCalculation (:98-99), then the neighbours' rho for the ghosts
-        self._check(L.sph_bucket_generation(self._ctx))
-        self._check(L.sph_density_calculation(self._ctx))
-        self._refresh(N.SPH_SLAB_UPDATE_RHO, 1, ex_l, ex_r, gh_l, gh_r)
-        # 4. sub-steps (:101-102); ghosts follow their owners after each but the last
-        dt = float(np.float32(deltaTime) / np.float32(self.dt_divisor))
-        for i in range(self.substeps):
-            self._check(L.sph_update_velocity_and_position(self._ctx, dt))
-            if i + 1 < self.substeps:
-                self._refresh(N.SPH_SLAB_UPDATE_POSVEL, N.SPH_SLAB_POSVEL_WORDS, ex_l, ex_r, gh_l, gh_r)
+        self._check(N.lib().sph_slab_step(self._ctx, float(np.float32(deltaTime))))
         self.frames += 1
-
-    def _refresh(self, what, words, ex_l, ex_r, gh_l, gh_r):
-        L, T = N.lib(), self.transport
-        sl, sr = self._send
-        p = lambda t: C.c_void_p(t.data_ptr())
-        self._check(L.sph_slab_pack_update(self._ctx, what, p(sl), p(sr)))
-        rl, rr = T.exchange(sl[:ex_l * words], sr[:ex_r * words], gh_l * words, gh_r * words, sl)
-        self._check(L.sph_slab_unpack_update(self._ctx, what, p(rl), p(rr)))
 
     def step_n(self, deltaTime: float, frames: int):
         for _ in range(frames):
             self.Update(deltaTime)
+
+    def finish(self):
+        """Collective: validates the frame in flight (re-running it with a wider halo if needed)."""
+        self._check(N.lib().sph_slab_finish(self._ctx))
 
     # -- results ------------------------------------------------------------------------------------------
     def download_local(self):
@@ -263,13 +271,14 @@ class SlabSimulation:
         return ids[:k].copy(), pos[:k].copy(), vel[:k].copy(), rho[:k].copy()
 
     def gather(self, n_global: int, dst: int = 0):
-        """Full id-ordered arrays on rank dst (None elsewhere)."""
+        """Full id-ordered arrays on rank dst (None elsewhere).  Collective."""
         local = self.download_local()
         if self.world == 1:
             parts = [local]
         else:
+            import torch.distributed as dist
             parts = [None] * self.world if self.rank == dst else None
-            self.transport.dist.gather_object(local, parts, dst=dst, group=self.transport.group)
+            dist.gather_object(local, parts, dst=dst, group=self.group)
             if self.rank != dst:
                 return None
         pos = np.full((n_global, 4), np.nan, np.float32)
@@ -284,13 +293,14 @@ class SlabSimulation:
         return pos, vel, rho
 
     def stats(self) -> dict:
+        """Collective (validates the frame in flight first)."""
         s = N.SphStats()
         self._check(N.lib().sph_get_stats(self._ctx, C.byref(s)))
         d = s.as_dict()
         c = (C.c_uint32 * 5)()
         self._check(N.lib().sph_slab_counts(self._ctx, c))
         d.update(owned=int(c[0]), ghosts_left=int(c[1]), ghosts_right=int(c[2]), exported_left=int(c[3]),
-                 exported_right=int(c[4]), capacity=self.capacity, planes=(self.z_lo, self.z_hi))
+                 exported_right=int(c[4]), capacity=self.capacity, planes=(self.z_lo, self.z_hi), transport=self.transport)
         return d
 
     def reset_stats(self):
@@ -314,66 +324,63 @@ class SlabSimulation:
 # ---- bench.py --gpus N (N > 1) ----------------------------------------------------------------------------
 
 def bench_main(a, n, R, fill, dt_frame, rank, world, local_rank):
-    """Strong scaling: the SAME n-particle dam-break split over `world` GPUs (one rank each)."""
+    """Strong scaling: the SAME n-particle dam-break split over `world` GPUs (one rank each).
+    Control plane: torch.distributed gloo on 127.0.0.1; halo: RCCL from inside the library."""
     import os
-    import torch
     import torch.distributed as dist
-    # rehearsal hooks (tests / one-GPU boxes): SPH_DIST_BACKEND=gloo stages the halo through the host,
-    # SPH_DIST_SINGLE_DEVICE=1 puts every rank on cuda:0.  The driver's runs use neither.
-    backend = os.environ.get("SPH_DIST_BACKEND", "nccl")
+    # rehearsal hooks (tests / one-GPU boxes): SPH_DIST_TRANSPORT=host stages the halo through the host (gloo),
+    # SPH_DIST_SINGLE_DEVICE=1 puts every rank on device 0.  The driver's runs use neither.
+    transport = os.environ.get("SPH_DIST_TRANSPORT", "auto")
     if os.environ.get("SPH_DIST_SINGLE_DEVICE") == "1":
         local_rank = 0
-    torch.cuda.set_device(local_rank)
-    if not dist.is_initialized() and world == 1:      # --force-slab diagnostic without a launcher
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29577")
-        dist.init_process_group("gloo", rank=0, world_size=1)
-    if not dist.is_initialized():
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29577")
+    os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")   # one node: RCCL's bootstrap needs no external interface
+    if not dist.is_initialized() and world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     pos0, vel0 = presets.dam_break(n, fill, a.seed)
     sim = SlabSimulation(rank, world, n, R, fill, 0.01, 1.5, 150.0, 5000.0, 10.0, device_id=local_rank,
-                         halo_w=2, profile=True).Start(pos0, vel0)
+                         halo_w=2, profile=True, transport=transport).Start(pos0, vel0)
     del pos0, vel0
+    ctl = sim.control
     warm = max(a.warmup, 1)
     sim.step_n(dt_frame, warm)
+    sim.finish()
     sim.synchronize()
     sim.reset_stats()
-    dist.barrier()
-    torch.cuda.synchronize()
+    ctl.barrier()
     t0 = time.perf_counter()
     sim.step_n(dt_frame, a.steps)
-    torch.cuda.synchronize()
-    dist.barrier()
-    elapsed = sim.transport.all_reduce(time.perf_counter() - t0, "max")
+    sim.finish()
+    sim.synchronize()
+    ctl.barrier()
+    elapsed = ctl.all_reduce(time.perf_counter() - t0, "max")
     st = sim.stats()
-    viol = sim.transport.all_reduce(float(st["halo_violations"]), "sum")
-    owned_max = sim.transport.all_reduce(float(st["owned"]), "max")
-    ghosts = sim.transport.all_reduce(float(st["ghosts_left"] + st["ghosts_right"]), "sum")
+    viol = ctl.all_reduce(float(st["halo_violations"]), "sum")
+    owned_max = ctl.all_reduce(float(st["owned"]), "max")
+    ghosts = ctl.all_reduce(float(st["ghosts_left"] + st["ghosts_right"]), "sum")
     vel_ms = st["ms_velpos"] / max(st["launches_velpos"], 1)
     listed = st.get("launches_velpos_list", 0) > 0
     kernel = "k_velpos_list" if listed else "k_velpos_brick"
     kernel_ms = st["ms_velpos_list"] / st["launches_velpos_list"] if listed else vel_ms
     value = n * a.steps / elapsed
+    achieved = 52.0 * st["owned"] / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
     out = {
         "metric": "particle-steps/s", "value": value, "unit": "particle-steps/s", "n_gpus": world, "steps": a.steps,
         "warmup": warm, "ms_per_step": elapsed * 1e3 / a.steps, "higher_is_better": True, "scaling": "strong",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "", "particles": n, "bucket_resolution": R, "substeps": 5, "mode": "exact_order",
-                   "decomposition": f"{world} z-slabs, halo {sim.halo_w} planes, p2p ghost exchange over "
-                                    f"torch.distributed/{dist.get_backend()}"},
-        "roofline": {"bound": "hbm", "kernel": kernel + " (rank 0)",
-                     "achieved": 52.0 * st["owned"] / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0, "peak": 8000.0,
-                     "unit": "GB/s", "frac": (52.0 * st["owned"] / (kernel_ms * 1e-3) / 1e9 / 8000.0) if kernel_ms > 0 else 0.0,
-                     "traffic": None, "kernel_ms": kernel_ms},
+                   "decomposition": f"{world} z-slabs, halo {st['halo_planes']} planes, in-library neighbour exchange "
+                                    f"({sim.transport}), torch.distributed/gloo control plane"},
+        "roofline": {"bound": "hbm", "kernel": kernel + " (rank 0)", "achieved": achieved, "peak": 8000.0,
+                     "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None, "kernel_ms": kernel_ms},
         "neighbour_lists_rank0": {"listed_fraction_of_target_substeps":
                                   st.get("listed_target_substeps", 0) / max(st["owned"] * st["launches_velpos"], 1)},
-        "halo_violations": viol, "max_owned_per_rank": owned_max, "ghost_particles_total": ghosts,
+        "halo_violations": viol, "frames_rerun": st["frames_rerun"], "host_syncs_per_frame_rank0": st["host_syncs"] / max(a.steps, 1),
+        "max_owned_per_rank": owned_max, "ghost_particles_total": ghosts,
         "passes_ms_rank0": {"grid": st["ms_grid"] / max(st["launches_grid"], 1),
                             "density": st["ms_density"] / max(st["launches_density"], 1), "velpos": vel_ms},
     }
     sim.OnDestroy()
-    dist.barrier()
+    ctl.barrier()
     return out

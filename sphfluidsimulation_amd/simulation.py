@@ -29,7 +29,8 @@ class SphFluidSimulation:
                  gasConstant: float = 150.0, stiffnessCoefficient: float = 5000.0,
                  dampingCoefficient: float = 10.0, device_id: int = 0, profile: bool = False,
                  tiling: bool = True, lists: bool = True, graphs: bool = True, particleRadius: float = 0.01, lowSpeed: float = 0.0,
-                 highSpeed: float = 0.5):
+                 highSpeed: float = 0.5, substeps: int = 5, device_ids=None, halo_planes: int = 0, list_skin: float = 0.0,
+                 peer_copies: bool = False):
         # inspector fields and defaults, SphFluidSimulation.cs:35-45
         self.preset = preset
         self.particleNumber = particleNumber
@@ -50,6 +51,11 @@ class SphFluidSimulation:
         self.lists = lists              # False: every sub-step re-scans its 27 bins (SPH_FLAG_NO_LISTS); "always":
                                         # record lists every frame instead of only while they pay (SPH_FLAG_LISTS_ALWAYS)
         self.graphs = graphs            # False: no HIP-graph replay of whole frames (SPH_FLAG_NO_GRAPHS)
+        self.substeps = substeps        # 5, SphFluidSimulation.cs:101
+        self.device_ids = list(device_ids) if device_ids else None   # 2..8 ordinals: z-slabs on several GPUs of this process
+        self.halo_planes = halo_planes  # ghost planes per slab face to start with (0 = 2)
+        self.list_skin = list_skin      # neighbour-list skin / h (0 = 0.04)
+        self.peer_copies = peer_copies  # multi-device: peer-to-peer copies instead of RCCL (SPH_FLAG_PEER_COPIES)
         self._ctx = C.c_void_p()
         self._derived = None
 
@@ -65,9 +71,16 @@ class SphFluidSimulation:
         p.stiffness_coeff = self.stiffnessCoefficient
         p.damping_coeff = self.dampingCoefficient
         p.device_id = self.device_id
+        p.substeps = int(self.substeps)
+        p.halo_planes = int(self.halo_planes)
+        p.list_skin = float(self.list_skin)
+        if self.device_ids:
+            p.num_devices = len(self.device_ids)
+            for k, dev in enumerate(self.device_ids):
+                p.device_ids[k] = int(dev)
         p.flags = ((N.SPH_FLAG_PROFILE if self.profile else 0) | (0 if self.tiling else N.SPH_FLAG_NO_TILING) |
                    (0 if self.lists else N.SPH_FLAG_NO_LISTS) | (0 if self.graphs else N.SPH_FLAG_NO_GRAPHS) |
-                   (N.SPH_FLAG_LISTS_ALWAYS if self.lists == "always" else 0))
+                   (N.SPH_FLAG_LISTS_ALWAYS if self.lists == "always" else 0) | (N.SPH_FLAG_PEER_COPIES if self.peer_copies else 0))
         return p
 
     def _check(self, rc):

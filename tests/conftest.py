@@ -3,6 +3,14 @@ import sys
 
 import pytest
 
+# PyTorch bundles its own HIP runtime and RCCL images.  Loaded FIRST, libsph_hip.so binds to them (same sonames) and the
+# process holds ONE runtime image; loaded after it, the process would map two (the cause of the same-process import crash
+# of round 1, see tests/test_mesh_properties.py).  The product itself never needs torch.
+try:
+    import torch  # noqa: F401
+except Exception:  # pragma: no cover
+    torch = None
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

@@ -1,5 +1,5 @@
-"""CPU coverage of the N > 1 path: slab partition logic and the neighbour transport over gloo
-(world_size 2 and 3, ragged and empty messages).  The device side is covered by
+"""CPU coverage of the N > 1 path: slab partition logic, the host transport the library calls back into (gloo,
+world_size 2 and 3, ragged and empty messages) and a world_size-2 launch of bench.py up to the point where it needs a GPU.  The device side is covered by
 tests/test_gpu_distributed.py."""
 import os
 import socket
@@ -61,10 +61,25 @@ def test_bucket_plane_matches_the_oracle_bucket(oracle):
 
 
 @pytest.mark.parametrize("world", [2, 3])
-def test_neighbour_transport_gloo(world):
+def test_host_transport_gloo(world):
     import torch.multiprocessing as mp
     from tests import dist_workers
     with tempfile.TemporaryDirectory() as d:
         mp.spawn(dist_workers.transport_worker, args=(world, free_port(), d), nprocs=world, join=True)
         for r in range(world):
             assert open(os.path.join(d, f"ok_{r}")).read() == "1", f"rank {r}"
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` started plainly (as the driver may do) must launch its two ranks itself, rendezvous on
+    127.0.0.1 and fail -- here, without a GPU -- loudly in the library, not in the launcher."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(HIP_VISIBLE_DEVICES="-1", ROCR_VISIBLE_DEVICES="-1", SPH_DIST_TRANSPORT="host")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--particles", "4096", "--steps", "1",
+                        "--warmup", "1"], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode != 0
+    assert "no HIP device available" in r.stderr and "no CPU fallback" in r.stderr, r.stderr[-2000:]
+    assert "must be launched with" not in r.stderr

@@ -1,11 +1,17 @@
-"""Multi-rank slab decomposition on ONE GPU (ranks share cuda:0, gloo with host-staged halo exchange):
-the N-slab result must be bit-identical to the CPU oracle (and therefore to the 1-GPU engine)."""
+"""z-slab decomposition on ONE GPU: the N-slab result must be bit-identical to the CPU oracle (and therefore to the 1-GPU
+engine).  Two routes into the same in-library frame driver (csrc/sph_slab_frame.hip):
+  * several slabs in ONE process behind the ordinary calls (SphParams.num_devices, device_ids = [0, 0, ...]: the halo moves
+    by device copies; with distinct devices the same code path runs RCCL),
+  * one process per slab, ranks sharing cuda:0, the library's host transport over gloo (sph_slab_set_host_transport).
+The RCCL transport needs one GPU per rank; a one-rank communicator (no neighbours) is what can be exercised here."""
+import ctypes as C
 import os
 import tempfile
 
 import numpy as np
 import pytest
 
+from sphfluidsimulation_amd import _native as N
 from sphfluidsimulation_amd import presets
 from tests.test_distributed_cpu import free_port
 from tests.test_gpu_parity import SCENE, assert_parity
@@ -22,12 +28,16 @@ def run_slabs(world, n, R, frames, speed, halo_w=2, seed=21):
         return dict(np.load(os.path.join(d, "slab.npz")))
 
 
-def oracle_frames(oracle, n, R, frames, speed, seed=21):
-    fill = 0.8
-    pos0, vel0 = presets.dam_break(n, fill, seed)
+def initial_state(n, speed, seed=21):
+    pos0, vel0 = presets.dam_break(n, 0.8, seed)
     if speed:
         vel0[:, :3] = np.random.default_rng(5).normal(0, speed, (vel0.shape[0], 3)).astype(np.float32)
-    ora = oracle.OracleSimulation(oracle.derive(n, R, fill, **SCENE))
+    return pos0, vel0
+
+
+def oracle_frames(oracle, n, R, frames, speed, seed=21):
+    pos0, vel0 = initial_state(n, speed, seed)
+    ora = oracle.OracleSimulation(oracle.derive(n, R, 0.8, **SCENE))
     ora.upload(pos0, vel0)
     out = [(pos0, vel0, np.zeros(pos0.shape[0], np.float32))]
     for _ in range(frames):
@@ -36,12 +46,17 @@ def oracle_frames(oracle, n, R, frames, speed, seed=21):
     return out
 
 
+def group_engine(n, R, slabs, halo=0, **kw):
+    from sphfluidsimulation_amd.simulation import SphFluidSimulation
+    return SphFluidSimulation(particleNumber=n, bucketResolution=R, damFillRate=0.8, device_ids=[0] * slabs, halo_planes=halo, **kw)
+
+
 @pytest.mark.parametrize("world,n,R,speed", [(2, 32768, 24, 0.0), (3, 32768, 24, 3.0), (4, 262144, 47, 1.0)])
 def test_slabs_match_oracle(oracle, world, n, R, speed):
     frames = 3
     got = run_slabs(world, n, R, frames, speed)
     want = oracle_frames(oracle, n, R, frames, speed)
-    assert got["violations"] == 0
+    assert got["violations"] == 0 and got["reruns"] == 0
     assert got["owned_total"] == want[0][0].shape[0]          # nobody lost or duplicated by the migration
     assert got["ghosts"] > 0
     for f in range(frames + 1):
@@ -51,8 +66,160 @@ def test_slabs_match_oracle(oracle, world, n, R, speed):
             assert_parity(got[f"rho_f{f}"], want[f][2], f"{world} slabs frame {f}: rho")
 
 
-def test_halo_violation_is_reported():
-    """Particles fast enough to cross more than one plane per frame leave the 2-plane halo: the run
-    must say so instead of silently diverging."""
-    got = run_slabs(2, 32768, 24, 2, speed=60.0)
-    assert got["violations"] > 0
+@pytest.mark.parametrize("slabs,n,R,speed", [(2, 32768, 24, 0.0), (3, 32768, 24, 3.0), (4, 262144, 47, 1.0), (8, 262144, 47, 0.5)])
+def test_multi_device_context_matches_oracle(oracle, slabs, n, R, speed):
+    """SphParams.num_devices behind the ORDINARY calls (what a C# host uses): sph_create / sph_upload / sph_step /
+    sph_download, bit-identical to the oracle, one host synchronisation per frame."""
+    frames = 4
+    pos0, vel0 = initial_state(n, speed)
+    sim = group_engine(n, R, slabs).Start(pos0, vel0)
+    want = oracle_frames(oracle, n, R, frames, speed)
+    dt = presets.bench_dt_frame(R)
+    try:
+        p, v, _ = sim.download()
+        assert_parity(p, want[0][0], "upload round trip: pos")
+        assert_parity(v, want[0][1], "upload round trip: vel")
+        sim.reset_stats()
+        for f in range(1, frames + 1):
+            sim.Update(dt)
+            if f in (1, frames):
+                p, v, r = sim.download()
+                assert_parity(p, want[f][0], f"{slabs} slabs frame {f}: pos")
+                assert_parity(v, want[f][1], f"{slabs} slabs frame {f}: vel")
+                assert_parity(r, want[f][2], f"{slabs} slabs frame {f}: rho")
+        st = sim.stats()
+        assert st["frames"] == frames and st["substeps"] == 5 * frames
+        assert st["halo_violations"] == 0 and st["frames_rerun"] == 0 and st["halo_planes"] == 2
+        # one synchronisation per frame + one per collective read-back (2 downloads, 1 stats); the target was <= 2 per frame
+        assert st["host_syncs"] <= frames + 3, st["host_syncs"]
+    finally:
+        sim.OnDestroy()
+
+
+def test_halo_violation_is_repaired(oracle):
+    """Particles fast enough to outrun a 2-plane halo: the frame is re-run with a wider one and the result is STILL
+    bit-identical to the oracle -- through both routes."""
+    n, R, speed, frames = 32768, 24, 5.0, 3
+    want = oracle_frames(oracle, n, R, frames, speed)
+    pos0, vel0 = initial_state(n, speed)
+    sim = group_engine(n, R, 2).Start(pos0, vel0)
+    dt = presets.bench_dt_frame(R)
+    try:
+        for f in range(1, frames + 1):
+            sim.Update(dt)
+        p, v, r = sim.download()
+        st = sim.stats()
+        assert st["frames_rerun"] >= 1 and st["halo_planes"] > 2, (st["frames_rerun"], st["halo_planes"], st["halo_violations"])
+        assert_parity(p, want[frames][0], "repaired run: pos")
+        assert_parity(v, want[frames][1], "repaired run: vel")
+        assert_parity(r, want[frames][2], "repaired run: rho")
+    finally:
+        sim.OnDestroy()
+    got = run_slabs(2, n, R, frames, speed)
+    assert got["reruns"] >= 1 and got["halo"] > 2
+    for f in range(frames + 1):
+        assert_parity(got[f"pos_f{f}"], want[f][0], f"repaired 2 ranks frame {f}: pos")
+        assert_parity(got[f"vel_f{f}"], want[f][1], f"repaired 2 ranks frame {f}: vel")
+
+
+def test_halo_cannot_grow_is_an_error():
+    """Slabs too thin for the halo the flow needs: a loud error, never a silently different result."""
+    n, R = 32768, 24
+    pos0, vel0 = initial_state(n, 60.0)
+    sim = group_engine(n, R, 4).Start(pos0, vel0)       # 6 planes per slab: the halo cannot exceed 3
+    try:
+        with pytest.raises(N.SphError) as e:
+            for _ in range(3):
+                sim.Update(presets.bench_dt_frame(R))
+            sim.download()
+        assert e.value.code in (N.SPH_E_COMM, N.SPH_E_OOM)
+    finally:
+        sim.OnDestroy()
+
+
+def test_ghosts_carry_wild_values(oracle):
+    """An inf velocity next to a slab face: the neighbour slab sees it only as a ghost and must still take the literal loop
+    (inf * 0 = NaN poisons its neighbours exactly as in the single-GPU run)."""
+    n, R, frames = 32768, 24, 2
+    pos0, vel0 = initial_state(n, 0.0)
+    cz = np.floor(pos0[:, 2] * (R - 1)).astype(int)
+    face = np.nonzero(cz == R // 2 - 1)[0]               # last plane of slab 0 of 2
+    vel0[face[len(face) // 2], 0] = np.inf
+    ora = oracle.OracleSimulation(oracle.derive(n, R, 0.8, **SCENE))
+    ora.upload(pos0, vel0)
+    sim = group_engine(n, R, 2).Start(pos0, vel0)
+    try:
+        for _ in range(frames):
+            ora.Update(presets.bench_dt_frame(R))
+            sim.Update(presets.bench_dt_frame(R))
+        po, vo, ro = ora.download()
+        p, v, r = sim.download()
+        assert np.isnan(vo).any() or (vo[:, 3] == np.float32(0.003)).any()   # the poison did spread in the reference semantics
+        assert_parity(p, po, "inf ghost: pos")
+        assert_parity(v, vo, "inf ghost: vel")
+    finally:
+        sim.OnDestroy()
+
+
+def test_rccl_transport_one_rank():
+    """The RCCL route end to end as far as one GPU allows: librccl loads, a communicator of one rank is created from a unique
+    id, and a slab without neighbours steps through sph_slab_step (its frame protocol, the all-reduce included)."""
+    from sphfluidsimulation_amd.simulation import SphFluidSimulation
+    os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")    # RCCL's bootstrap: one node, no external interface needed
+    n, R = 16384, 19
+    pos0, vel0 = presets.dam_break(n, 0.8, 3)
+    L = N.lib()
+    ident = C.create_string_buffer(N.SPH_COMM_ID_BYTES)
+    N.check(L.sph_comm_unique_id(ident))
+    p = N.default_params()
+    p.num_particles, p.bucket_resolution, p.dam_fill_rate = n, R, 0.8
+    ctx = C.c_void_p()
+    N.check(L.sph_slab_create(C.byref(p), n + 64, C.byref(ctx)))
+    try:
+        N.check(L.sph_slab_configure(ctx, 0, 1), ctx)
+        N.check(L.sph_slab_comm_init(ctx, ident), ctx)
+        ids = np.arange(n, dtype=np.uint32)
+        fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
+        N.check(L.sph_slab_upload(ctx, n, fp(pos0), fp(vel0), ids.ctypes.data_as(C.POINTER(C.c_uint32))), ctx)
+        dt = presets.bench_dt_frame(R)
+        for _ in range(2):
+            N.check(L.sph_slab_step(ctx, C.c_float(dt)), ctx)
+        oid = np.empty(n + 64, np.uint32)
+        op = np.empty((n + 64, 4), np.float32)
+        ov = np.empty((n + 64, 4), np.float32)
+        orho = np.empty(n + 64, np.float32)
+        k = C.c_uint32()
+        N.check(L.sph_slab_download(ctx, n + 64, oid.ctypes.data_as(C.POINTER(C.c_uint32)), fp(op), fp(ov), fp(orho), C.byref(k)), ctx)
+        assert k.value == n
+        info = N.runtime_info()
+        assert info["rccl_version"] > 0 and "librccl" in info["rccl_library_path"]
+    finally:
+        L.sph_destroy(ctx)
+    ref = SphFluidSimulation(particleNumber=n, bucketResolution=R, damFillRate=0.8).Start(pos0, vel0)
+    for _ in range(2):
+        ref.Update(dt)
+    pr, vr, rr = ref.download()
+    ref.OnDestroy()
+    order = np.argsort(oid[:n])
+    assert np.array_equal(oid[:n][order], ids)
+    assert_parity(op[:n][order], pr, "one-rank RCCL slab vs plain context: pos")
+    assert_parity(ov[:n][order], vr, "one-rank RCCL slab vs plain context: vel")
+    assert_parity(orho[:n][order], rr, "one-rank RCCL slab vs plain context: rho")
+
+
+def test_bench_two_ranks_as_the_driver_launches_it():
+    """`python bench.py --gpus 2` exactly as the driver may start it (no launcher): two rank processes, gloo control plane,
+    here with both ranks on the one GPU and the host transport (RCCL needs a GPU per rank)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(SPH_DIST_TRANSPORT="host", SPH_DIST_SINGLE_DEVICE="1")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--particles", "262144", "--steps", "3",
+                        "--warmup", "2"], capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["value"] > 0 and out["halo_violations"] == 0
+    assert "host" in out["config"]["decomposition"]

@@ -191,3 +191,28 @@ def test_gpu_mesh_properties_zero_copy_export():
         os.close(fd.value)
     finally:
         sim.OnDestroy()
+
+
+@pytest.mark.gpu
+def test_gpu_mesh_properties_same_process_import():
+    """Row f4 as a Unity host would use it: the fd is imported in the process that exported it, through the SAME HIP runtime
+    image libsph_hip.so is bound to (sph_runtime_info names it) and with typed arguments.  Round 1 crashed here: its test
+    asked ctypes for "libamdhip64.so" in a process that had mapped a second runtime image (PyTorch's bundled one) next to
+    the system runtime the library used -- a handle exported by one image was imported through the other
+    (tests/import_fd_same_process.py two-images reproduces that layout; profiles/ records what it does)."""
+    import os
+    import subprocess
+    import sys
+    script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "import_fd_same_process.py")
+    env = {k: v for k, v in os.environ.items() if k != "PYTHONPATH"}
+    r = subprocess.run([sys.executable, script, "same"], capture_output=True, text=True, env=env, timeout=600)
+    lines = r.stdout.splitlines()
+    if any(l.startswith("UNSUPPORTED") for l in lines):
+        pytest.skip("no exportable device memory on this system")
+    assert r.returncode == 0 and "DONE" in lines, (r.returncode, r.stdout[-1500:], r.stderr[-1500:])
+    images = [l for l in lines if l.startswith("HIP_IMAGES")][0].split()
+    assert images[1] == "1", images                       # one runtime image in the process
+    sums = {l.split()[1]: l.split()[2:] for l in lines if l.startswith("CHECKSUM")}
+    for phase in ("before", "after"):
+        assert sums[phase][:2] == sums[phase][2:], (phase, sums)   # the import sees what the library wrote, also after an update
+    assert sums["before"] != sums["after"]
