@@ -27,6 +27,7 @@ public:
     // rendering fields :49-53 (SampleScene.unity:372-376)
     float particleRadius = 0.01f, lowSpeed = 0.0f, highSpeed = 0.5f;
     int deviceId = 0;
+    std::vector<int> deviceIds;   // 2..8 HIP ordinals: the particles are split into z-slabs over these GPUs (same calls)
 
     ~SphFluidSimulation() { OnDestroy(); }
 
@@ -133,6 +134,10 @@ private:
         p.stiffness_coeff = stiffnessCoefficient;
         p.damping_coeff = dampingCoefficient;
         p.device_id = deviceId;
+        if (deviceIds.size() >= 2 && deviceIds.size() <= 8) {
+            p.num_devices = (uint32_t)deviceIds.size();
+            for (size_t k = 0; k < deviceIds.size(); k++) p.device_ids[k] = deviceIds[k];
+        }
         return p;
     }
 

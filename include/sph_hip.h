@@ -187,7 +187,10 @@ int sph_mesh_properties_device_ptr(SphContext *ctx, void **device_ptr, size_t *b
  * VK_KHR_external_memory_fd, which is what Unity's Linux renderer would use for _particleMeshPropertiesBuffer, or
  * another process through hipMemImportFromShareableHandle.  The caller owns (closes) the fd; the memory lives until
  * sph_destroy; `bytes` is the size of the allocation (num_particles * 80 rounded up to the device's granularity).
- * Later sph_update_mesh_properties calls write into the exported memory.  SPH_E_UNSUPPORTED if the driver cannot export. */
+ * Later sph_update_mesh_properties calls write into the exported memory.  SPH_E_UNSUPPORTED if the driver cannot export.
+ * Importing in the SAME process works (tests/test_mesh_properties.py::test_gpu_mesh_properties_same_process_import) as long as the
+ * importer uses the HIP runtime image this library is bound to (sph_runtime_info): a second libamdhip64 image in the process
+ * sees no device at all and faults -- the cause of round 1's crash (profiles/r02_fd_import_two_runtime_images.txt). */
 int sph_export_mesh_properties_fd(SphContext *ctx, int *fd, size_t *bytes);
 
 /* One Update() (SphFluidSimulation.cs:96-102) with Time.deltaTime = delta_time:

@@ -6,8 +6,8 @@ using System;
 using System.Runtime.InteropServices;
 using UnityEngine;   // Matrix4x4 in SphMeshParams
 
-// (Not bound here: sph_set_stream and the sph_slab_* entry points -- the z-slab mode is driven by one process per GPU with
-// a halo exchange between them, sphfluidsimulation_amd/distributed.py; a single Unity process has no use for it.)
+// (Not bound here: sph_set_stream and the sph_slab_* / sph_comm_* entry points of the one-process-per-GPU mode.  A single
+// Unity process reaches several GPUs through SphParams.num_devices / device_id0..7 and the SAME calls as below.)
 public static class SphNative
 {
     const string Lib = "sph_hip";
@@ -18,7 +18,7 @@ public static class SphNative
     [StructLayout(LayoutKind.Sequential)]
     public struct SphParams
     {
-        public uint struct_size;        // = Marshal.SizeOf<SphParams>() (76)
+        public uint struct_size;        // = Marshal.SizeOf<SphParams>() (120)
         public uint num_particles;      // particleNumber,        SphFluidSimulation.cs:36
         public uint bucket_resolution;  // bucketResolution,      :37
         public float dam_fill_rate;     // damFillRate,           :38
@@ -35,6 +35,12 @@ public static class SphNative
         public uint exact_order;
         public int device_id;
         public uint flags;
+        // ABI version 2: 2..8 = split the particles into that many z-slabs, slab i on HIP device device_id<i> (RCCL halo
+        // exchange inside the library); Update() / GetData calls are unchanged
+        public uint num_devices;
+        public int device_id0, device_id1, device_id2, device_id3, device_id4, device_id5, device_id6, device_id7;  // int32_t device_ids[8]
+        public uint halo_planes;        // 0 = default (2); grows automatically when particles outrun it
+        public float list_skin;         // 0 = default (0.04)
     }
 
     [StructLayout(LayoutKind.Sequential)]
@@ -55,6 +61,7 @@ public static class SphNative
         public ulong listed_target_substeps, scanned_brick_substeps, list_entries;
         public double ms_velpos_list;
         public ulong launches_velpos_list, graph_replays, frames_without_lists;
+        public ulong host_syncs, frames_rerun, halo_planes;
     }
 
     [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int sph_version();

@@ -139,22 +139,27 @@ def test_halo_cannot_grow_is_an_error():
 
 def test_ghosts_carry_wild_values(oracle):
     """An inf velocity next to a slab face: the neighbour slab sees it only as a ghost and must still take the literal loop
-    (inf * 0 = NaN poisons its neighbours exactly as in the single-GPU run)."""
-    n, R, frames = 32768, 24, 2
+    (inf * 0 = NaN resets the out-of-range listed neighbours exactly as in the single-GPU run).  Two sub-steps only: in
+    the reference's semantics the poisoned particles are then thrown across the whole box (wall damping subtracts inf from
+    every component, VelPos.compute:135), which no halo can follow -- that case is the loud error of the test above."""
+    n, R = 32768, 24
     pos0, vel0 = initial_state(n, 0.0)
     cz = np.floor(pos0[:, 2] * (R - 1)).astype(int)
     face = np.nonzero(cz == R // 2 - 1)[0]               # last plane of slab 0 of 2
     vel0[face[len(face) // 2], 0] = np.inf
-    ora = oracle.OracleSimulation(oracle.derive(n, R, 0.8, **SCENE))
+    op = oracle.derive(n, R, 0.8, **SCENE)
+    op.substeps = 2
+    ora = oracle.OracleSimulation(op)
     ora.upload(pos0, vel0)
-    sim = group_engine(n, R, 2).Start(pos0, vel0)
+    sim = group_engine(n, R, 2, substeps=2).Start(pos0, vel0)
     try:
-        for _ in range(frames):
-            ora.Update(presets.bench_dt_frame(R))
-            sim.Update(presets.bench_dt_frame(R))
+        ora.Update(presets.bench_dt_frame(R))
+        sim.Update(presets.bench_dt_frame(R))
         po, vo, ro = ora.download()
         p, v, r = sim.download()
-        assert np.isnan(vo).any() or (vo[:, 3] == np.float32(0.003)).any()   # the poison did spread in the reference semantics
+        assert (vo[:, 3] != np.float32(2.0)).sum() > 10               # the NaN guard fired around the wild particle ...
+        owner1 = np.floor(pos0[:, 2] * (R - 1)).astype(int) >= R // 2
+        assert (vo[owner1, 3] != np.float32(2.0)).any()               # ... also in the slab that only sees it as a ghost
         assert_parity(p, po, "inf ghost: pos")
         assert_parity(v, vo, "inf ghost: vel")
     finally:

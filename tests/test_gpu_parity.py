@@ -305,7 +305,8 @@ def test_cpp_host_mirror_runs():
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     exe = os.path.join(root, "host", "sph_host_demo")
-    if not os.path.exists(exe):
+    deps = [os.path.join(root, "include", f) for f in ("sph_hip.h", "SphFluidSimulation.hpp")] + [os.path.join(root, "host", "sph_host_demo.cpp")]
+    if not os.path.exists(exe) or any(os.path.getmtime(d) > os.path.getmtime(exe) for d in deps):   # (a stale binary has the old SphParams)
         import __graft_entry__
         __graft_entry__.build()
     out = subprocess.run([exe, "262144", "47", "4"], capture_output=True, text=True, timeout=300)
