@@ -133,6 +133,8 @@ typedef struct SphStats {
     uint64_t host_syncs;              /* host <-> device synchronisations issued by slab frames (one per frame)  */
     uint64_t frames_rerun;            /* frames run again with a wider halo after a violation                     */
     uint64_t halo_planes;             /* ghost planes per face in use now                                         */
+    uint64_t list_row_entries;        /* neighbour-list rows: entries per particle now (grown when lists do not fit)  */
+    uint64_t lists_too_long;          /* targets of the last recording frame whose list did not fit (their bricks scan) */
 } SphStats;
 
 typedef struct SphContext SphContext;

@@ -61,7 +61,7 @@ public static class SphNative
         public ulong listed_target_substeps, scanned_brick_substeps, list_entries;
         public double ms_velpos_list;
         public ulong launches_velpos_list, graph_replays, frames_without_lists;
-        public ulong host_syncs, frames_rerun, halo_planes;
+        public ulong host_syncs, frames_rerun, halo_planes, list_row_entries, lists_too_long;
     }
 
     [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int sph_version();

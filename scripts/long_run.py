@@ -17,4 +17,5 @@ for f0 in range(0, frames, chunk):
     st = sim.stats()
     print(f"frames {f0+1}-{f0+chunk}: {el/chunk*1e3:7.2f} ms/frame  grid {st['ms_grid']/chunk:5.2f} density {st['ms_density']/chunk:5.2f} "
           f"velpos {st['ms_velpos']/(5*chunk):5.2f} listed {st['listed_target_substeps']/(5.0*chunk*n):5.3f}  max_occ {st['max_cell_occupancy']} overflow_cells {st['overflowed_cells']} "
-          f"queued {st['queued_targets']} nan {st['nan_resets']} P-bar {st['candidates_density']/n:6.1f}", flush=True)
+          f"queued {st['queued_targets']} nan {st['nan_resets']} P-bar {st['candidates_density']/n:6.1f} rows {st['list_row_entries']} too_long {st['lists_too_long']} "
+          f"scanned_bricks/substep {st['scanned_brick_substeps']/(5*chunk):.0f} entries/listed {st['list_entries']/max(st['listed_target_substeps'],1):.1f} nolist_frames {st['frames_without_lists']}", flush=True)

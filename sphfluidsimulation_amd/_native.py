@@ -105,6 +105,8 @@ class SphStats(C.Structure):
         ("host_syncs", C.c_uint64),
         ("frames_rerun", C.c_uint64),
         ("halo_planes", C.c_uint64),
+        ("list_row_entries", C.c_uint64),
+        ("lists_too_long", C.c_uint64),
     ]
 
     def as_dict(self):

@@ -22,6 +22,9 @@ HEADERS = ["sph_internal.hpp", "sph_sweep_common.hpp", "sph_fastdiv.hpp", "sph_c
 FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
     "-ffp-contract=off", "-fno-fast-math", "-fhip-fp32-correctly-rounded-divide-sqrt",
+    # the SLP vectoriser packs pairs of independent fp32 operations into v_pk_* instructions, which take two issue slots
+    # and schedule worse than the scalar pair on gfx950 (k_velpos_list 2.11 -> 2.00 ms)
+    "-fno-slp-vectorize",
     "-Wall", "-Wno-unused-function",
 ]
 

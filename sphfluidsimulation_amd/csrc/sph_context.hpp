@@ -52,6 +52,8 @@ struct SphContext {
     uint64_t frames_since_upload = 0, graph_replays = 0;
     // frame-coherent neighbour lists (sph_kernels_list.hip)
     bool nl_enabled = false, nl_allocated = false;
+    uint32_t nl_cap_want = 64;        // entries per list row (grown when frames report longer lists, grow_list_rows)
+    unsigned long long nl_hold_until = 0;   // frames issued when the rows were last re-allocated
     bool nl_unavailable = false;      // the list buffers could not be allocated once: never tried again
     bool nl_fresh = false;            // the grid was just built: the next density pass runs on the binned positions
     bool nl_recorded = false;         // ... and recorded the lists the VelPos sub-steps of this frame may use
@@ -70,6 +72,7 @@ struct SphContext {
                                       // otherwise pay for 20 frames of a probe that fails)
     unsigned long long pol_issued = 0;   // frames issued with a report kernel
     int pol_low_streak = 0, pol_high_streak = 0;
+    double pol_min_frac = 0.9;        // lists stay on while they serve at least this share of the target sub-steps
     uint64_t pol_backoff = 8, pol_resume_at = 0, pol_frames_off = 0;
     float nl_skin_frac = 0.04f;       // skin / h (profiles/: 0.04-0.06 is the optimum of the 16.7 M dam break)
     float4 *mesh_props = nullptr;     // _particleMeshPropertiesBuffer (:174), allocated on first use
@@ -112,6 +115,7 @@ struct SphContext {
 inline void reset_list_policy(SphContext *c)
 {
     const bool big = c->dev.R >= 100u;
+    c->pol_min_frac = big ? 0.5 : 0.9;
     c->pol_on = big || (c->params.flags & SPH_FLAG_LISTS_ALWAYS);
     c->pol_confirmed = false;
     c->pol_low_streak = c->pol_high_streak = 0;

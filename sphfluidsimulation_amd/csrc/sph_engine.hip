@@ -191,7 +191,7 @@ static void ensure_lists(SphContext *c)
         return;
     }
     const size_t bricks = (size_t)nl_bricks_x(d.R) * nl_bricks_y(d.R) * nl_bricks_z(d.R);
-    d.nl_cap = 64;
+    d.nl_cap = c->nl_cap_want;
     d.n_bricks = (uint32_t)bricks;
     d.n_chunks = (uint32_t)((n + kChunkSlots - 1) / kChunkSlots);
     const size_t before = c->allocs.size();
@@ -284,6 +284,37 @@ int do_velpos(SphContext *c, float dt)
     c->substeps_since_upload++;
     c->dt_last = dt;
     return SPH_OK;
+}
+
+// Lists longer than the entry rows leave their whole brick scanning (crowded regions of a collapsed dam: ~130 candidates within
+// h where the calm fluid has ~18).  When a frame reports many of them the rows are re-allocated twice as long (64 -> 128 -> 256
+// entries; 4 B x nl_cap per particle, only the used part is ever touched).  Never inside a capture; frame graphs re-capture
+// by themselves because the launch state (Dev) changes.
+static void grow_list_rows(SphContext *c)
+{
+    if (!c->report_host || !c->nl_allocated || c->slab || c->nl_cap_want >= 256u) return;
+    const unsigned long long too_long = c->report_host[3];
+    const unsigned long long many = c->dev.count / 4096u > 64u ? c->dev.count / 4096u : 64u;
+    if (too_long < many || c->report_host[0] <= c->nl_hold_until) return;   // (only frames issued with the current rows count)
+    Dev &d = c->dev;
+    const uint32_t cap = c->nl_cap_want * 2u;
+    const size_t n = c->capacity;
+    uint32_t *rows = nullptr;
+    (void)hipStreamSynchronize(c->stream);
+    if (hipMalloc((void **)&rows, (size_t)cap * ((n + 63) & ~(size_t)63) * sizeof(uint32_t)) != hipSuccess) {
+        (void)hipGetLastError();
+        c->nl_cap_want = 256u;        // (no memory for longer rows: stop asking)
+        return;
+    }
+    for (void *&p : c->allocs)
+        if (p == (void *)d.nl_ent) {
+            (void)hipFree(p);
+            p = rows;
+        }
+    d.nl_ent = rows;
+    d.nl_cap = cap;
+    c->nl_cap_want = cap;
+    c->nl_hold_until = c->pol_issued;
 }
 
 // ---- C ABI -----------------------------------------------------------------------------------------
@@ -681,8 +712,11 @@ static void update_list_policy(SphContext *c)
         if (dlf > 0 && listed >= c->pol_seen[1] && c->frames_since_upload > 3) {
             const double frac = (double)(listed - c->pol_seen[1]) / ((double)dlf * (double)c->dev.count * (double)c->params.substeps);
             if (c->pol_on) {
-                // (the first sub-step of a frame is always served: 0.9 of all means 0.875 of the sub-steps that can fail)
-                if (frac < 0.9) {
+                // Break-even: recording + keeping the lists valid costs ~2 ms per frame at 16.7 M and a served target sub-step
+                // saves ~0.11 ns against the scanning brick kernel -> ~0.25 of the target sub-steps at 16.7 M, more in small
+                // boxes whose kernels are launch-bound (R < 100: the old 0.9).  Late in a dam break the crowded wall cells are
+                // scanned anyway while the calm bulk (60-90 %) is still served three times faster (profiles/r02_long_run_16M.txt).
+                if (frac < c->pol_min_frac) {
                     c->pol_high_streak = 0;
                     if (++c->pol_low_streak >= 2) {
                         c->pol_on = false;
@@ -737,6 +771,7 @@ int sph_step(SphContext *c, float delta_time)
     const float dt = delta_time / c->params.dt_divisor;                 // :102 Time.deltaTime / 25
     update_list_policy(c);
     if (c->pol_on) ensure_lists(c);   // (never inside a stream capture)
+    grow_list_rows(c);
     if (frame_reports(c)) c->pol_issued++;
     // the first two frames after an upload run ungraphed: they allocate (neighbour lists) and settle the pointer parity
     const bool graphed = c->graphs_enabled && c->own_stream && c->uploaded && c->frames_since_upload >= 2 && c->params.substeps > 0;
@@ -890,6 +925,8 @@ int engine_get_stats(SphContext *c, SphStats *out)
     out->listed_target_substeps = stat[kStatListed];
     out->scanned_brick_substeps = cnt[kCntActiveBricks];
     out->list_entries = stat[kStatListEntries];
+    out->list_row_entries = c->nl_allocated ? c->dev.nl_cap : 0;
+    out->lists_too_long = cnt[kCntListTooLong];
     out->host_syncs = c->host_syncs;
     out->frames_rerun = c->group ? slab_group_reruns(c->group) : 0;
     out->halo_planes = c->slab ? (uint64_t)c->halo_w : 0;
@@ -944,6 +981,17 @@ int sph_debug_read_order(SphContext *c, void *dst, size_t bytes)
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     HIP_TRY(c, hipMemcpy(dst, c->dev.order, bytes, hipMemcpyDeviceToHost));
+    return SPH_OK;
+}
+#endif
+
+#ifdef SPH_DEBUG_API   /* diagnostic builds only (scripts/list_balance.py): raw read of the neighbour-list counts */
+int sph_debug_read_list_counts(SphContext *c, void *dst, size_t bytes)
+{
+    if (!c || !dst || !c->dev.nl_cnt) return SPH_E_INVALID_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemcpy(dst, c->dev.nl_cnt, bytes, hipMemcpyDeviceToHost));
     return SPH_OK;
 }
 #endif

@@ -114,6 +114,7 @@ enum Counter : int {
     kCntActiveCount,    // length of active_list for the sub-step in flight
     kCntQueue2,         // length of queue2 (targets k_velpos_list hands to k_velpos_list_changers) for the sub-step in flight
     kCntIrregular,      // last grid build saw a position outside [0,1] (or NaN): bins say nothing about positions
+    kCntListTooLong,    // targets of the last recording density pass whose list exceeded nl_cap (their bricks scan)
     kCntCount
 };
 

@@ -231,6 +231,11 @@ __device__ __forceinline__ void walk_list_and_integrate(const Dev &d, uint32_t s
             const Cand b0 = gather(w2), b1 = gather(w3);
             w2 = word(e + 4);
             w3 = word(e + 5);
+#if defined(SPH_ABLATE) && SPH_ABLATE == 7   /* diagnostic: the gathers without the pair arithmetic (0.40 of 2.0 ms) */
+            f.px += a0.x + a0.rho; f.py += a0.y + a0.vx; f.pz += a1.z + a1.vy; f.vx += a1.vz + a1.x;
+            a0 = b0; a1 = b1;
+            continue;
+#endif
             // (the list kernels never run in a wild launch: nl_blocked)
             const PairPre q0 = pair_pre<true>(d, pix - a0.x, piy - a0.y, piz - a0.z, a0.rho, a0.vx, a0.vy, a0.vz, vix, viy, viz,
                                               p_i, a0.take);                     // :86-95
@@ -248,7 +253,11 @@ __device__ __forceinline__ void walk_list_and_integrate(const Dev &d, uint32_t s
 // frame's first sub-step.  Slot order keeps every per-target stream (9 loads, 6 stores, the 256 B entry rows) fully
 // coalesced; the candidates of 64 consecutive slots (~17 bins of one row and their neighbours, ~20 KB of
 // (x,y,z,-) + (rho,vx,vy,vz)) are gathered through L1/L2 -- there is no tile to stage.  The pair arithmetic
-// (~160 VALU instructions per entry, 14 IEEE divisions per two entries) is what bounds the kernel.
+// (~125 VALU instructions per entry; 14 quotients per two entries from 4 refined reciprocals, sph_fastdiv.hpp) is what
+// bounds the kernel: 1.6 of its 2.0 ms (SPH_ABLATE=7 leaves the gathers: 0.4 ms).  A wave runs as long as its longest list
+// (mean 17.8 entries, mean of the per-wave maxima 24.7: scripts/list_balance.py); dealing the slots of a workgroup to its
+// waves by list length cuts the trips by 19 % but ran 20-40 % SLOWER, stable or not (round 2): lanes that are no longer
+// spatial neighbours gather 64 unrelated cache lines per instruction.  Consecutive slots per wave stay.
 __global__ void __launch_bounds__(kListBlock, SPH_LIST_MINWAVES) k_velpos_list(Dev d)
 {
     __shared__ uint32_t s_queue[2];
@@ -322,7 +331,8 @@ __global__ void __launch_bounds__(kBlock) k_velpos_list_changers(Dev d)
 
 // End of a frame: how many target sub-steps the lists served so far, into host-visible memory (no synchronisation: the
 // engine's list policy reads it whenever it next issues a frame).  report[0] frames reported, [1] listed target
-// sub-steps (cumulative since the last statistics reset), [2] frames of those that recorded lists.
+// sub-steps (cumulative since the last statistics reset), [2] frames of those that recorded lists, [3] targets of the
+// last recording frame whose list exceeded nl_cap (the engine then re-allocates longer rows).
 __global__ void __launch_bounds__(kStatStripes) k_frame_report(Dev d, unsigned long long *report, int lists_in_use)
 {
     __shared__ unsigned long long s_part[kStatStripes / kWave];
@@ -335,6 +345,7 @@ __global__ void __launch_bounds__(kStatStripes) k_frame_report(Dev d, unsigned l
         for (int w = 0; w < kStatStripes / kWave; w++) total += s_part[w];
         report[1] = total;
         report[2] += lists_in_use ? 1ull : 0ull;
+        if (lists_in_use) report[3] = d.counters[kCntListTooLong];   // targets whose list did not fit nl_cap this frame
         __threadfence_system();
         report[0] += 1ull;                         // last: the host takes [1], [2] only as fresh as [0]
         __threadfence_system();

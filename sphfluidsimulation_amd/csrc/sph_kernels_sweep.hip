@@ -24,23 +24,45 @@ constexpr int kQueueGrid = 2048;      // blocks of the queue kernels (grid-strid
 
 // ---- Density.compute:29-60 for target slot s -------------------------------------------------------
 
+// RECORD (the density pass of a fresh grid with neighbour lists on, sph_kernels_list.hip): the candidates within h + skin
+// also go to the target's list, exactly as k_density_brick<RECORD> writes them -- crowded regions (cells at the 32-cap,
+// whose 27-cell neighbourhoods never fit an LDS tile) are where a list saves most: ~130 entries instead of 864 candidates
+// in each of the frame's five sub-steps.
+template <bool RECORD>
 __device__ __forceinline__ uint32_t density_target(const Dev &d, uint32_t s)
 {
     const float pix = d.cur.x[s], piy = d.cur.y[s], piz = d.cur.z[s];
     const int R = (int)d.R;
     const int ix = cell_coord(pix, d.Rm1, R), iy = cell_coord(piy, d.Rm1, R), iz = cell_coord(piz, d.Rm1, R);
     float rho = 0.0f;
-    uint32_t visited = 0;
+    uint32_t visited = 0, gn = 0;
+    uint32_t *nl_row = RECORD ? nl_entries(d, s) : nullptr;
     for (int xo = -1; xo <= 1; xo++)
         for (int yo = -1; yo <= 1; yo++)
             for (int zo = -1; zo <= 1; zo++) {
                 const CellRange cr = cell_range(d, ix + xo, iy + yo, iz + zo);
                 visited += cr.cnt;
+                const uint32_t code = (uint32_t)(((xo + 1) * 3 + (yo + 1)) * 3 + (zo + 1));
                 for (uint32_t k = 0; k < cr.cnt; k++) {
                     const uint32_t j = cr.start + k;
-                    rho += density_term(d, pix - d.cur.x[j], piy - d.cur.y[j], piz - d.cur.z[j]);
+                    const float rx = pix - d.cur.x[j], ry = piy - d.cur.y[j], rz = piz - d.cur.z[j];
+                    const float r2 = (rx * rx + ry * ry) + rz * rz;              // Density.compute:24
+                    rho += density_term_r2(d, r2);
+                    if (RECORD && r2 < d.h2_list) {                              // superset of |r| < h + skin
+                        if (gn < d.nl_cap) nl_row[gn * kWave] = (code << kNlSlotBits) | j;
+                        gn++;
+                    }
                 }
             }
+    if (RECORD) {
+        if (gn <= d.nl_cap) d.nl_cnt[s] = (uint16_t)gn;
+        else {                                                                   // list too long: its brick keeps scanning
+            const uint32_t ux = (uint32_t)(ix < 0 ? 0 : (ix > R - 1 ? R - 1 : ix)), uy = (uint32_t)(iy < 0 ? 0 : (iy > R - 1 ? R - 1 : iy)),
+                           uz = (uint32_t)(iz < 0 ? 0 : (iz > R - 1 ? R - 1 : iz));
+            d.brick_state[ux / kNlBX + nl_bricks_x(d.R) * (uy / kNlBY + nl_bricks_y(d.R) * (uz / kNlBZ))] = kBrickUnlisted;
+            atomicAdd(&d.counters[kCntListTooLong], 1ull);
+        }
+    }
     d.cur.rv[s].x = rho;                                                         // :59
     // pressure that a later VelPos pass derives from this density (VelPos.compute:61,87)
     if (is_wild_density(d, rho)) d.counters[kCntWildP] = 1ull;
@@ -85,7 +107,13 @@ __device__ __forceinline__ void velpos_target(const Dev &d, uint32_t s, bool liv
                 const CellRange cr = cell_range(d, ix + xo, iy + yo, iz + zo);
                 for (uint32_t k = 0; k < cr.cnt; k++) {
                     const uint32_t j = cr.start + k;
-                    const float rx = pix - d.cur.x[j], ry = piy - d.cur.y[j], rz = piz - d.cur.z[j];
+                    float rx, ry, rz;
+                    if (d.cur.p4) {                      // (wave-uniform) the packed copy: one 16-byte load instead of three
+                        const float4 pj = d.cur.p4[j];
+                        rx = pix - pj.x; ry = piy - pj.y; rz = piz - pj.z;
+                    } else {
+                        rx = pix - d.cur.x[j]; ry = piy - d.cur.y[j]; rz = piz - d.cur.z[j];
+                    }
                     const float r2 = (rx * rx + ry * ry) + rz * rz;
                     if (j != s && r2 < d.h2_up) {        // superset of |r| < h (VelPos.compute:37,43)
                         list[(((n >> 1) * kBlock + tid) << 1) + (n & 1u)] = (uint16_t)((ci << 5) | k);
@@ -117,7 +145,7 @@ __global__ void __launch_bounds__(kBlock) k_density_exact(Dev d)
 {
     const uint32_t s = blockIdx.x * kBlock + threadIdx.x;
     unsigned long long v = 0;
-    if (s < d.count && !(d.ghost && d.ghost[s])) v = density_target(d, s);
+    if (s < d.count && !(d.ghost && d.ghost[s])) v = density_target<false>(d, s);   // (no bricks: no lists)
     stat_add(d, kStatCandidates, v);
 }
 
@@ -139,7 +167,8 @@ __global__ void __launch_bounds__(kBlock) k_density_queue(Dev d)
     unsigned long long v = 0;
     for (uint32_t q0 = blockIdx.x * kBlock; q0 < qlen; q0 += gridDim.x * kBlock) {
         const uint32_t q = q0 + threadIdx.x;
-        if (q < qlen && !(d.ghost && d.ghost[d.queue[q]])) v += density_target(d, d.queue[q]);
+        if (q < qlen && !(d.ghost && d.ghost[d.queue[q]]))
+            v += d.nl_mode == kNlBuild ? density_target<true>(d, d.queue[q]) : density_target<false>(d, d.queue[q]);
     }
     stat_add(d, kStatCandidates, v);
 }

@@ -45,7 +45,7 @@ def test_struct_layouts_match_header(native):
     assert (p.rest_density, p.gas_constant, p.stiffness_coeff, p.damping_coeff) == (1.5, 150.0, 5000.0, 10.0)
     assert p.dt_divisor == 25.0 and abs(p.gravity[1] + 9.8) < 1e-6 and p.gravity[0] == 0 and p.gravity[2] == 0
     assert C.sizeof(native.SphDerived) == 9 * 4
-    assert C.sizeof(native.SphStats) == 8 * 8 + 4 * 4 + 13 * 8
+    assert C.sizeof(native.SphStats) == 8 * 8 + 4 * 4 + 15 * 8
     assert native.lib().sph_version() == 2
     assert (p.num_devices, p.halo_planes, p.list_skin) == (0, 0, 0.0) and list(p.device_ids) == [0] * 8
 
