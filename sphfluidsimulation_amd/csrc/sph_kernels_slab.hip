@@ -18,6 +18,7 @@ namespace sph {
 
 constexpr int kBlock = 256;
 constexpr uint32_t kNoTag = 0xFFFFFFFFu;
+constexpr int kClassifyBlock = 1024;   // one atomic on the keeper counter per workgroup: ~3 ns each on that single address
 
 __device__ __forceinline__ void write_record(float *buf, uint32_t k, const Dev &d, uint32_t p, uint32_t tag)
 {
@@ -59,15 +60,23 @@ __device__ __forceinline__ uint32_t block_append(bool pred, uint32_t *counter, u
 //     W boundary planes stay here as ghosts (`kept`), so that the neighbour need not send them back: the tag tells it
 //     which entry of the later refresh messages they are.
 // counters: see SlabCounter.
-__global__ void __launch_bounds__(kBlock) k_slab_classify(Dev d, SlabArgs a)
+__global__ void __launch_bounds__(kClassifyBlock) k_slab_classify(Dev d, SlabArgs a)
 {
     __shared__ uint32_t s_cnt[2];
-    const uint32_t s = blockIdx.x * kBlock + threadIdx.x;
+    const uint32_t s = blockIdx.x * kClassifyBlock + threadIdx.x;
     int dest = -1;                                     // 0 keep, 1 to the left neighbour, 2 to the right one
     int cz = 0;
     bool in_grid = false;
+    // every load of the particle is issued before the first barrier of the compaction (one latency, not two)
+    float px = 0.0f, py = 0.0f, pz = 0.0f, pvw = 0.0f;
+    float4 prv = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    uint32_t pid = 0;
     if (s < d.count && !d.ghost[s]) {
-        const uint32_t key = bucket_key(d, d.cur.x[s], d.cur.y[s], d.cur.z[s]);
+        px = d.cur.x[s]; py = d.cur.y[s]; pz = d.cur.z[s];
+        prv = d.cur.rv[s];
+        pvw = d.cur.vw[s];
+        pid = d.id[s];
+        const uint32_t key = bucket_key(d, px, py, pz);
         dest = 0;
         in_grid = key < d.num_cells;
         if (in_grid) {
@@ -81,10 +90,10 @@ __global__ void __launch_bounds__(kBlock) k_slab_classify(Dev d, SlabArgs a)
     if (lost) atomicAdd(&a.counters[kSlabLost], 1u);
     const uint32_t k = block_append(dest == 0, &a.counters[kSlabKeep], s_cnt);
     if (dest == 0) {
-        d.nxt.x[k] = d.cur.x[s]; d.nxt.y[k] = d.cur.y[s]; d.nxt.z[k] = d.cur.z[s];
-        d.nxt.rv[k] = d.cur.rv[s];
-        d.nxt.vw[k] = d.cur.vw[s];
-        d.id_nxt[k] = d.id[s];
+        d.nxt.x[k] = px; d.nxt.y[k] = py; d.nxt.z[k] = pz;
+        d.nxt.rv[k] = prv;
+        d.nxt.vw[k] = pvw;
+        d.id_nxt[k] = pid;
     }
 #pragma unroll
     for (int side = 0; side < 2; side++) {
@@ -248,7 +257,7 @@ static inline dim3 grid_for(uint32_t n) { return dim3(n ? cdiv(n, kBlock) : 1u);
 
 void launch_slab_classify(const Dev &d, const SlabArgs &a, uint32_t *hdr_send, unsigned long long *viol, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_slab_classify, grid_for(d.count), dim3(kBlock), 0, s, d, a);
+    hipLaunchKernelGGL(k_slab_classify, dim3(d.count ? cdiv(d.count, kClassifyBlock) : 1u), dim3(kClassifyBlock), 0, s, d, a);
     hipLaunchKernelGGL(k_slab_headers, dim3(1), dim3(64), 0, s, d, a, hdr_send, viol);
 }
 

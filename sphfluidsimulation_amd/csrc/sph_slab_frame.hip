@@ -721,14 +721,9 @@ static int phase_payload(SlabGroup &g)
         }
         m->dev.count = at;
         G_HIP(g, hipGetLastError());
-        // the owned particles as the frame finds them: what a re-run with a wider halo starts from
+        // (the owned particles as the frame finds them -- what a re-run with a wider halo starts from -- are parked by
+        // phase_compute once the grid build has read them: no copy)
         const size_t n = m->dev.n_owned;
-        G_HIP(g, hipMemcpyAsync(r->snap_x, m->dev.cur.x, n * sizeof(float), hipMemcpyDeviceToDevice, m->stream));
-        G_HIP(g, hipMemcpyAsync(r->snap_y, m->dev.cur.y, n * sizeof(float), hipMemcpyDeviceToDevice, m->stream));
-        G_HIP(g, hipMemcpyAsync(r->snap_z, m->dev.cur.z, n * sizeof(float), hipMemcpyDeviceToDevice, m->stream));
-        G_HIP(g, hipMemcpyAsync(r->snap_vw, m->dev.cur.vw, n * sizeof(float), hipMemcpyDeviceToDevice, m->stream));
-        G_HIP(g, hipMemcpyAsync(r->snap_rv, m->dev.cur.rv, n * sizeof(float4), hipMemcpyDeviceToDevice, m->stream));
-        G_HIP(g, hipMemcpyAsync(r->snap_id, m->dev.id, n * sizeof(uint32_t), hipMemcpyDeviceToDevice, m->stream));
         r->snap_n = (uint32_t)n;
         r->snap_substeps = m->substeps_since_upload;
         r->snap_dt_last = m->dt_last;
@@ -777,6 +772,16 @@ static int phase_compute(SlabGroup &g, float delta_time)
         G_HIP(g, hipSetDevice(m->device));
         m->dev.dt_ptr = nullptr;
         if ((rc = do_bucket_generation(m)) != SPH_OK) return rc;   // :98
+        // The build gathered the particles into sorted order; the arrays it read (owned particles first, as the frame found
+        // them) become the snapshot a re-run starts from, and the previous snapshot's arrays the new scratch set: three
+        // sets rotate, nothing is copied.
+        SlabRank *r = m->rank;
+        std::swap(m->dev.nxt.x, r->snap_x);
+        std::swap(m->dev.nxt.y, r->snap_y);
+        std::swap(m->dev.nxt.z, r->snap_z);
+        std::swap(m->dev.nxt.vw, r->snap_vw);
+        std::swap(m->dev.nxt.rv, r->snap_rv);
+        std::swap(m->dev.id_nxt, r->snap_id);
         if ((rc = do_density(m)) != SPH_OK) return rc;             // :99
     }
     if ((rc = refresh_ghosts(g, SPH_SLAB_UPDATE_RHO)) != SPH_OK) return rc;
