@@ -53,6 +53,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--particles", type=int, default=16777216)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--precision", type=int, default=0, help="1: positions stored as fp16 cell offsets (BASELINE config 5), arithmetic fp32")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the S = 1 variant and the late-phase (frames 281-300) figure")
     ap.add_argument("--force-slab", action="store_true", help="diagnostic: run the z-slab driver even with one rank")
@@ -178,7 +179,7 @@ def main():
     pos0, vel0 = presets.dam_break(n, fill, a.seed)
     sim = SphFluidSimulation(particleNumber=n, bucketResolution=R, damFillRate=fill, viscosity=0.01,
                              restDensity=1.5, gasConstant=150.0, stiffnessCoefficient=5000.0,
-                             dampingCoefficient=10.0, device_id=0, profile=True).Start(pos0, vel0)
+                             dampingCoefficient=10.0, device_id=0, profile=True, precision=a.precision).Start(pos0, vel0)
 
     # GPU result after CPU_FRAMES frames, checked against the CPU baseline run below; then start over for the timing
     warm = a.warmup
@@ -257,7 +258,9 @@ def main():
     listed = st["launches_velpos_list"] > 0
     kernel = "k_velpos_list" if listed else "k_velpos_brick"
     kernel_ms = st["ms_velpos_list"] / st["launches_velpos_list"] if listed else vel_ms
-    achieved = BYTES_PER_SUBSTEP * n / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+    bytes_substep = BYTES_PER_SUBSTEP if a.precision == 0 else 40     # (6 + 12 + 4) R + (6 + 12) W with fp16 positions
+    bytes_step = (32 + 52 * 5) if a.precision == 0 else (20 + 40 * 5)
+    achieved = bytes_substep * n / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
     traffic, traffic_src = pmc_traffic(kernel) if n == 16777216 else (None, None)
     insts, trans, insts_src = pmc_valu(kernel) if n == 16777216 else (None, None, None)
     # transcendental instructions (v_rcp, v_sqrt) hold the issue port four times as long as the rest
@@ -272,13 +275,13 @@ def main():
         "steps": a.steps, "warmup": warm, "ms_per_step": ms_per_step, "higher_is_better": True,
         "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": workload, "particles": n, "bucket_resolution": R, "substeps": 5,
-                   "mode": "exact_order"},
+                   "mode": "exact_order", "positions": "fp32" if a.precision == 0 else "fp16 offsets from the cell centre (stored), fp32 arithmetic"},
         "roofline": {
             "bound": "valu" if (issue_frac or 0.0) > hbm_frac else "hbm", "kernel": kernel, "achieved": achieved,
             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_frac, "traffic": traffic, "traffic_source": traffic_src,
-            "algorithmic_bytes_per_launch": BYTES_PER_SUBSTEP * n,
+            "algorithmic_bytes_per_launch": bytes_substep * n,
             "kernel_ms": kernel_ms, "launches": st["launches_velpos_list"] if listed else st["launches_velpos"],
-            "step_hbm_frac": value * (32 + 52 * 5) / (HBM_PEAK_GBS * 1e9),
+            "step_hbm_frac": value * bytes_step / (HBM_PEAK_GBS * 1e9),
             "valu_issue_frac": issue_frac, "valu_insts_per_launch": insts, "valu_source": insts_src,
             "valu_frac_executed_pair_flops": exec_flops / 1e12 / VALU_PEAK_TFLOPS,
             "valu_frac_nominal_candidates": value * pbar * (FLOPS_DENSITY + FLOPS_FORCE * 5) / 1e12 / VALU_PEAK_TFLOPS,
@@ -307,6 +310,7 @@ def main():
         base, (po, vo, ro) = cpu_baseline(n, R, fill, pos0, vel0, dt_frame)
         out["cpu_baseline"] = base
         out["parity_frames"] = CPU_FRAMES
+        out["parity_bar"] = "bit-identical (0.0)" if a.precision == 0 else "1e-4 (positions are stored rounded)"
         out["parity_max_abs_diff"] = {"pos": float(np.abs(parity_state[0] - po).max()), "vel": float(np.abs(parity_state[1] - vo).max()),
                                       "rho": float(np.abs(parity_state[2] - ro).max())}
     sim.OnDestroy()

@@ -65,7 +65,9 @@ typedef struct SphParams {
     uint32_t substeps;          /* 5  (:101)                                                        */
     float dt_divisor;           /* 25 (:102)                                                        */
     float gravity[3];           /* (0,-9.8,0) VelPos.compute:7                                      */
-    uint32_t precision;         /* 0 = fp32 state (only value supported in this ABI version)        */
+    uint32_t precision;         /* 0 = fp32 state (bit-identical to the CPU oracle); 1 = positions stored as fp16 offsets
+                                   from the centre of the particle's grid cell (8 B instead of 12), all arithmetic and the
+                                   velocities fp32 -- BASELINE config 5; within 1e-4 of the fp32 result after a frame         */
     uint32_t exact_order;       /* 1 = accumulate neighbours in the reference's x,y,z / slot order  */
     int32_t device_id;          /* HIP device ordinal (num_devices <= 1)                            */
     uint32_t flags;             /* SPH_FLAG_*                                                       */

@@ -68,6 +68,7 @@ void refresh_scalars(SphContext *c)
     d.gy = p.gravity[1];
     d.gz = p.gravity[2];
     d.use_bricks = (p.flags & SPH_FLAG_NO_TILING) ? 0u : 1u;
+    d.prec = p.precision;
     // neighbour lists: skin = nl_skin_frac * h; pre-filter radius (h + skin)^2 rounded up like h2_up; a brick is calm
     // while its relative-displacement bound stays below 90 % of the skin (the rest absorbs fp32 rounding of the bound)
     c->nl_enabled = d.use_bricks && !(p.flags & SPH_FLAG_NO_LISTS) && d.R <= 256u && !c->nl_unavailable;
@@ -99,7 +100,9 @@ static int validate(SphContext *ctx, const SphParams *p)
         return fail(ctx, SPH_E_UNSUPPORTED, "max_per_voxel must be 32 (MaxParticlesPerVoxel)");
     if (p->substeps == 0 || p->substeps > 1000) return fail(ctx, SPH_E_INVALID_ARG, "substeps out of range");
     if (!(p->dt_divisor > 0.0f)) return fail(ctx, SPH_E_INVALID_ARG, "dt_divisor must be > 0");
-    if (p->precision != 0) return fail(ctx, SPH_E_UNSUPPORTED, "precision %u not supported (fp32 only)", p->precision);
+    if (p->precision > 1) return fail(ctx, SPH_E_UNSUPPORTED, "precision %u not supported (0 = fp32, 1 = fp16 positions)", p->precision);
+    if (p->precision == 1 && p->num_devices > 1)
+        return fail(ctx, SPH_E_UNSUPPORTED, "precision 1 (fp16 positions) is single-device in this version");
     if (p->exact_order != 1) return fail(ctx, SPH_E_UNSUPPORTED, "exact_order=0 (fast mode) is not built in this version");
     if (p->num_devices > 8) return fail(ctx, SPH_E_INVALID_ARG, "num_devices %u > 8", p->num_devices);
     if (p->halo_planes > 128) return fail(ctx, SPH_E_INVALID_ARG, "halo_planes %u > 128", p->halo_planes);
@@ -120,9 +123,14 @@ static int dalloc(SphContext *c, T **out, size_t n)
 static int alloc_soa(SphContext *c, Soa *s, size_t n)
 {
     int rc;
-    float **f[] = {&s->x, &s->y, &s->z, &s->vw};
-    for (auto pp : f)
-        if ((rc = dalloc(c, pp, n)) != SPH_OK) return rc;
+    if (c->params.precision == 0) {
+        float **f[] = {&s->x, &s->y, &s->z};
+        for (auto pp : f)
+            if ((rc = dalloc(c, pp, n)) != SPH_OK) return rc;
+    } else if ((rc = dalloc(c, &s->h4, n)) != SPH_OK) {   // fp16 offsets from the slot's reference cell: 8 bytes instead of 12
+        return rc;
+    }
+    if ((rc = dalloc(c, &s->vw, n)) != SPH_OK) return rc;
     return dalloc(c, &s->rv, n);
 }
 
@@ -195,7 +203,9 @@ static void ensure_lists(SphContext *c)
     d.n_bricks = (uint32_t)bricks;
     d.n_chunks = (uint32_t)((n + kChunkSlots - 1) / kChunkSlots);
     const size_t before = c->allocs.size();
-    const bool ok = dalloc(c, &d.p1x, n) == SPH_OK && dalloc(c, &d.p1y, n) == SPH_OK && dalloc(c, &d.p1z, n) == SPH_OK &&
+    const bool binned = d.prec ? dalloc(c, &d.p1h, n) == SPH_OK
+                               : dalloc(c, &d.p1x, n) == SPH_OK && dalloc(c, &d.p1y, n) == SPH_OK && dalloc(c, &d.p1z, n) == SPH_OK;
+    const bool ok = binned &&
                     dalloc(c, &d.nl_ent, (size_t)d.nl_cap * ((n + 63) & ~(size_t)63)) == SPH_OK && dalloc(c, &d.nl_cnt, n) == SPH_OK &&
                     dalloc(c, &d.chunk_box, 6 * ((n + kChunkSlots - 1) / kChunkSlots)) == SPH_OK &&
                     dalloc(c, &d.active_list, bricks) == SPH_OK && dalloc(c, &d.queue2, n) == SPH_OK && dalloc(c, &d.brick_state, bricks) == SPH_OK &&
@@ -207,6 +217,7 @@ static void ensure_lists(SphContext *c)
         }
         (void)hipGetLastError();
         d.p1x = d.p1y = d.p1z = nullptr;
+        d.p1h = nullptr;
         d.nl_ent = nullptr;
         d.nl_cnt = nullptr;
         d.chunk_box = nullptr;
@@ -236,6 +247,7 @@ int do_bucket_generation(SphContext *c)
     HIP_TRY(c, hipGetLastError());
     std::swap(c->dev.cur, c->dev.nxt);
     std::swap(c->dev.id, c->dev.id_nxt);
+    std::swap(c->dev.cellkey, c->dev.cellkey_nxt);
     std::swap(c->dev.ghost, c->dev.ghost_nxt);
     c->grid_valid = true;
     c->frames++;
@@ -400,6 +412,14 @@ static int create_common(const SphParams *params, uint32_t capacity, bool slab, 
     A(alloc_soa(c, &d.nxt, n));
     A(dalloc(c, &d.id, n));
     A(dalloc(c, &d.id_nxt, n));
+    if (d.prec) {
+        if (slab) {
+            fail(c, SPH_E_UNSUPPORTED, "precision 1 (fp16 positions) is not available for z-slab contexts in this version");
+            return bail(SPH_E_UNSUPPORTED);
+        }
+        A(dalloc(c, &d.cellkey, n));
+        A(dalloc(c, &d.cellkey_nxt, n));
+    }
     A(dalloc(c, &d.key, n));
     A(dalloc(c, &d.cell_count, cells));
     A(dalloc(c, &d.cell_start, cells));
@@ -750,6 +770,7 @@ static void account_replayed_frame(SphContext *c, const SphContext::FrameGraph &
 {
     const uint32_t S = c->params.substeps;
     std::swap(c->dev.id, c->dev.id_nxt);                                // the grid build's swaps; cur/nxt: 1 + S swaps
+    std::swap(c->dev.cellkey, c->dev.cellkey_nxt);
     if ((1u + S) & 1u) std::swap(c->dev.cur, c->dev.nxt);
     if (S & 1u) c->dev.wild_v_cur ^= 1u;
     c->dev.force_slow = 0;
@@ -846,9 +867,9 @@ int sph_set_params(SphContext *c, const SphParams *p)
     int rc = validate(c, p);
     if (rc != SPH_OK) return rc;
     if (next_power_of_two(p->num_particles) != c->derived.num_particles || p->bucket_resolution != c->params.bucket_resolution ||
-        p->dam_fill_rate != c->params.dam_fill_rate || p->device_id != c->params.device_id)
+        p->dam_fill_rate != c->params.dam_fill_rate || p->device_id != c->params.device_id || p->precision != c->params.precision)
         return fail(c, SPH_E_INVALID_ARG,
-                    "num_particles / bucket_resolution / dam_fill_rate / device_id are fixed at sph_create");
+                    "num_particles / bucket_resolution / dam_fill_rate / device_id / precision are fixed at sph_create");
     if (p->gas_constant != c->params.gas_constant || p->rest_density != c->params.rest_density)
         c->dev.force_slow = 1;  // pressures change without a density pass: flag is stale until the next one
     if (p->num_devices != c->params.num_devices || p->halo_planes != c->params.halo_planes)

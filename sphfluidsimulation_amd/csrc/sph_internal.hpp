@@ -2,6 +2,7 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
 #include <stdint.h>
 
 namespace sph {
@@ -11,7 +12,10 @@ constexpr int kWave = 64;              // CDNA4 wavefront
 
 // One set of cell-sorted SoA particle arrays (ping-pong partner of another set).
 struct Soa {
-    float *x, *y, *z;     // position, SoA: what the neighbour scans stream (pos.w is derived, see k_download)
+    float *x, *y, *z;     // position, SoA: what the neighbour scans stream (pos.w is derived, see k_download); nullptr when
+                          // SphParams.precision = 1, see h4
+    uint2 *h4;            // precision 1 (config C4): position as an 8-byte record of three fp16 offsets (+ 3 x 5 sub-cell bits)
+                          // relative to the slot's reference cell (Dev::cellkey) instead of 12 bytes; arithmetic stays fp32 (load_pos)
     float4 *rv;           // (rho, vx, vy, vz) packed: ONE 16-byte gather per in-range pair in VelPos
     float4 *p4;           // (x, y, z, -) packed copy for the neighbour-list kernel's gathers; nullptr when lists are off
     float *vw;            // vel.w: sub-step counter / 0.003 NaN marker (VelPos.compute:146,150)
@@ -37,6 +41,11 @@ struct Dev {
     uint32_t wild_v_cur;   // which kCntWildV slot describes the velocities in `cur`
     uint32_t use_bricks;   // 1: LDS-tiled brick kernels + queue; 0: per-target kernels on global memory
     Soa cur, nxt;
+    uint32_t prec;         // SphParams.precision: 0 = fp32 positions, 1 = fp16 cell-relative positions
+    uint32_t *cellkey;     // precision 1: reference cell of every slot, (cx+2) | (cy+2) << 10 | (cz+2) << 20; the cell the particle
+                           //   was in when the slot was assigned (grid build / upload), fixed for a whole frame like `id`
+    uint32_t *cellkey_nxt; // written by the reorder, swapped with cellkey after a grid build
+    uint2 *p1h;            // precision 1: p1x/p1y/p1z as fp16 offsets (the binned positions of the neighbour lists)
     uint32_t *id;          // slot -> particle id (texel y*res + x); fixed for a whole frame
     uint32_t *id_nxt;      // written by the reorder, swapped with id after a grid build
     uint32_t *key;         // by slot (of cur, before the reorder)
@@ -154,6 +163,91 @@ __device__ __forceinline__ int cell_coord(float p, float Rm1, int R)
 {
     int c = hlsl_int(p * Rm1);
     return c < -2 ? -2 : (c > R + 1 ? R + 1 : c);
+}
+
+// ---- positions: fp32 SoA (precision 0) or an 8-byte fp16 record per slot (precision 1) -----------------------------------
+// Precision 1 stores a position relative to the slot's reference cell c (Dev::cellkey, fixed for the frame): with
+// u = p * (R-1) - c (in [0,1) right after a grid build, a cell or two beyond while the particle drifts inside the frame),
+//     sub = floor(8 u)  clamped to [-16, 15]          three 5-bit indices of an h/8 sub-cell, in the record's 4th half
+//     o   = 8 u - sub - 0.5  as IEEE half, RN          three fp16 offsets from that sub-cell's centre, |o| <= 0.5
+// i.e. the rounding of a stored position is <= 2^-13 of a sub-cell = 2^-16 of a cell (6e-8 of the box at R = 256, 3e-7 at
+// R = 47): plain fp16 offsets from the cell centre (2^-13 of a CELL) left the velocities 4e-4 off the fp32 oracle after ONE
+// sub-step -- the pressure term (h - r)^3 turns a relative position error of 2e-4 h into 2e-3 of the acceleration.
+// Every kernel reads positions through load_pos(), i.e. sees the SAME fp32 value for a slot, so which kernel served a
+// target still cannot change the result; only the stored state is rounded (integrate_store, the grid build, the upload).
+struct Pos3 {
+    float x, y, z;
+};
+__device__ __forceinline__ float half_bits_to_float(uint32_t h16) { return __half2float(__ushort_as_half((unsigned short)h16)); }
+__device__ __forceinline__ uint32_t float_to_half_bits(float f) { return (uint32_t)__half_as_ushort(__float2half_rn(f)); }
+__device__ __forceinline__ uint32_t pack_cellkey(int cx, int cy, int cz)   // coordinates in [-2, R+1] (cell_coord)
+{
+    return (uint32_t)(cx + 2) | (uint32_t)(cy + 2) << 10 | (uint32_t)(cz + 2) << 20;
+}
+constexpr float kSubCells = 8.0f;
+__device__ __forceinline__ Pos3 decode_pos(const Dev &d, uint2 o, uint32_t ck)
+{
+    const float cx = (float)((int)(ck & 1023u) - 2), cy = (float)((int)((ck >> 10) & 1023u) - 2), cz = (float)((int)(ck >> 20) - 2);
+    const uint32_t sub = o.y >> 16;
+    const float sx = (float)((int)(sub & 31u) - 16) + 0.5f, sy = (float)((int)((sub >> 5) & 31u) - 16) + 0.5f,
+                sz = (float)((int)((sub >> 10) & 31u) - 16) + 0.5f;
+    return Pos3{(cx + (sx + half_bits_to_float(o.x & 0xFFFFu)) * (1.0f / kSubCells)) * d.h,
+                (cy + (sy + half_bits_to_float(o.x >> 16)) * (1.0f / kSubCells)) * d.h,
+                (cz + (sz + half_bits_to_float(o.y & 0xFFFFu)) * (1.0f / kSubCells)) * d.h};
+}
+__device__ __forceinline__ uint2 encode_pos(const Dev &d, Pos3 p, uint32_t ck)
+{
+    const float cx = (float)((int)(ck & 1023u) - 2), cy = (float)((int)((ck >> 10) & 1023u) - 2), cz = (float)((int)(ck >> 20) - 2);
+    const float tx = (p.x * d.Rm1 - cx) * kSubCells, ty = (p.y * d.Rm1 - cy) * kSubCells, tz = (p.z * d.Rm1 - cz) * kSubCells;
+    const float sx = fminf(fmaxf(floorf(tx), -16.0f), 15.0f), sy = fminf(fmaxf(floorf(ty), -16.0f), 15.0f),
+                sz = fminf(fmaxf(floorf(tz), -16.0f), 15.0f);   // (NaN -> -16: the offset carries the NaN)
+    const uint32_t sub = (uint32_t)((int)sx + 16) | (uint32_t)((int)sy + 16) << 5 | (uint32_t)((int)sz + 16) << 10;
+    return make_uint2(float_to_half_bits(tx - sx - 0.5f) | float_to_half_bits(ty - sy - 0.5f) << 16,
+                      float_to_half_bits(tz - sz - 0.5f) | sub << 16);
+}
+__device__ __forceinline__ Pos3 load_pos(const Dev &d, const Soa &a, uint32_t j)
+{
+    if (d.prec == 0u) return Pos3{a.x[j], a.y[j], a.z[j]};
+    return decode_pos(d, a.h4[j], d.cellkey[j]);
+}
+__device__ __forceinline__ void store_pos(const Dev &d, const Soa &a, uint32_t s, Pos3 p)
+{
+    if (d.prec == 0u) {
+        a.x[s] = p.x; a.y[s] = p.y; a.z[s] = p.z;
+    } else {
+        a.h4[s] = encode_pos(d, p, d.cellkey[s]);
+    }
+}
+// the packed copy the neighbour-list kernels gather (Soa::p4): (x, y, z, -) fp32, or {offsets, reference cell} in precision 1
+template <int PREC>
+__device__ __forceinline__ Pos3 load_p4(const Dev &d, const Soa &a, uint32_t j)
+{
+    if (PREC == 0) {
+        const float4 q = a.p4[j];
+        return Pos3{q.x, q.y, q.z};
+    }
+    const uint4 q = reinterpret_cast<const uint4 *>(a.p4)[j];
+    return decode_pos(d, make_uint2(q.x, q.y), q.z);
+}
+__device__ __forceinline__ Pos3 load_p4(const Dev &d, const Soa &a, uint32_t j)
+{
+    return d.prec == 0u ? load_p4<0>(d, a, j) : load_p4<1>(d, a, j);
+}
+__device__ __forceinline__ void store_p4(const Dev &d, const Soa &a, uint32_t s, Pos3 p)
+{
+    if (d.prec == 0u) {
+        a.p4[s] = make_float4(p.x, p.y, p.z, 0.0f);
+    } else {
+        const uint32_t ck = d.cellkey[s];
+        const uint2 o = encode_pos(d, p, ck);
+        reinterpret_cast<uint4 *>(a.p4)[s] = make_uint4(o.x, o.y, ck, 0u);
+    }
+}
+// where the particle of slot s was when it was binned (neighbour lists)
+__device__ __forceinline__ Pos3 load_binned(const Dev &d, uint32_t s)
+{
+    if (d.prec == 0u) return Pos3{d.p1x[s], d.p1y[s], d.p1z[s]};
+    return decode_pos(d, d.p1h[s], d.cellkey[s]);
 }
 
 // launchers (sph_kernels_*.hip)

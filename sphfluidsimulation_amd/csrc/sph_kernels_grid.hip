@@ -27,7 +27,11 @@ __global__ void __launch_bounds__(kBlock) k_upload_split(Dev d, const float4 *__
     const float4 q = pos4[p];
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);        // ClearFloat4, SphFluidSimulation.cs:189
     if (vel4) v = vel4[p];
-    d.cur.x[p] = q.x; d.cur.y[p] = q.y; d.cur.z[p] = q.z;
+    if (d.prec) {                                      // reference cell of an uploaded particle: the cell it is in
+        const int R = (int)d.R;
+        d.cellkey[p] = pack_cellkey(cell_coord(q.x, d.Rm1, R), cell_coord(q.y, d.Rm1, R), cell_coord(q.z, d.Rm1, R));
+    }
+    store_pos(d, d.cur, p, Pos3{q.x, q.y, q.z});
     d.cur.rv[p] = make_float4(0.0f, v.x, v.y, v.z);    // density texture starts cleared
     d.cur.vw[p] = v.w;
     d.id[p] = p;                                       // id = y*res + x, Bucket.compute:24
@@ -48,7 +52,11 @@ __global__ void __launch_bounds__(kBlock) k_download_merge(Dev d, const float *_
     const float vw = d.cur.vw[s];
     // VelPos.compute:153-154: pos_out.w = clamp(1 + dt*vel_out.w, 0, 1); the uploaded w before that
     const float pw = substeps_done > 0 ? clamp01(1.0f + dt_last * vw) : pw0[id];
-    if (pos4) pos4[id] = make_float4(d.cur.x[s], d.cur.y[s], d.cur.z[s], pw);
+    if (pos4) {
+        Pos3 q = load_pos(d, d.cur, s);
+        if (d.prec && substeps_done > 0) q = Pos3{clamp01(q.x), clamp01(q.y), clamp01(q.z)};   // (VelPos.compute:154 clamped before the rounding)
+        pos4[id] = make_float4(q.x, q.y, q.z, pw);
+    }
     const float4 rv = d.cur.rv[s];
     if (vel4) vel4[id] = make_float4(rv.y, rv.z, rv.w, vw);
     if (rho_by_id) rho_by_id[id] = rv.x;
@@ -80,7 +88,8 @@ __global__ void __launch_bounds__(kBlock) k_cell_key_hist(Dev d)
     const bool valid = p < d.count;
     uint32_t key = 0xFFFFFFFFu;                                                // no cell: lanes past the end
     if (valid) {
-        const float x = d.cur.x[p], y = d.cur.y[p], z = d.cur.z[p];
+        const Pos3 q = load_pos(d, d.cur, p);
+        const float x = q.x, y = q.y, z = q.z;
         key = bucket_key(d, x, y, z);                                          // :26-29
         d.key[p] = key;
         if (!(x >= 0.0f && x <= 1.0f && y >= 0.0f && y <= 1.0f && z >= 0.0f && z <= 1.0f))
@@ -256,11 +265,25 @@ __global__ void __launch_bounds__(kBlock) k_reorder(Dev d)
     if (s >= d.count) return;
     const uint2 o = d.order[s];
     const uint32_t src = o.y;
-    const float x = d.cur.x[src], y = d.cur.y[src], z = d.cur.z[src];
-    d.nxt.x[s] = x; d.nxt.y[s] = y; d.nxt.z[s] = z;
-    if (d.p1x) {                                       // neighbour lists: where the particle was when it was binned
-        d.p1x[s] = x; d.p1y[s] = y; d.p1z[s] = z;
-        d.nxt.p4[s] = make_float4(x, y, z, 0.0f);
+    const Pos3 q = load_pos(d, d.cur, src);
+    const float x = q.x, y = q.y, z = q.z;
+    if (d.prec == 0u) {
+        d.nxt.x[s] = x; d.nxt.y[s] = y; d.nxt.z[s] = z;
+        if (d.p1x) {                                   // neighbour lists: where the particle was when it was binned
+            d.p1x[s] = x; d.p1y[s] = y; d.p1z[s] = z;
+            d.nxt.p4[s] = make_float4(x, y, z, 0.0f);
+        }
+    } else {
+        // the new slot's reference cell is the cell the particle is in NOW: offsets are back in [-0.5, 0.5]
+        const int R = (int)d.R;
+        const uint32_t ck = pack_cellkey(cell_coord(x, d.Rm1, R), cell_coord(y, d.Rm1, R), cell_coord(z, d.Rm1, R));
+        const uint2 o = encode_pos(d, q, ck);
+        d.cellkey_nxt[s] = ck;
+        d.nxt.h4[s] = o;
+        if (d.p1h) {
+            d.p1h[s] = o;
+            reinterpret_cast<uint4 *>(d.nxt.p4)[s] = make_uint4(o.x, o.y, ck, 0u);
+        }
     }
     d.nxt.rv[s] = d.cur.rv[src];                       // the density texture persists by id
     d.nxt.vw[s] = d.cur.vw[src];

@@ -47,7 +47,8 @@ __global__ void __launch_bounds__(kBlock) k_chunk_box(Dev d)
     const uint32_t s = blockIdx.x * kBlock + threadIdx.x;
     float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
     if (s < d.count) {
-        const float dl[3] = {d.cur.x[s] - d.p1x[s], d.cur.y[s] - d.p1y[s], d.cur.z[s] - d.p1z[s]};
+        const Pos3 pc = load_pos(d, d.cur, s), pb = load_binned(d, s);
+        const float dl[3] = {pc.x - pb.x, pc.y - pb.y, pc.z - pb.z};
 #pragma unroll
         for (int a = 0; a < 3; a++) lo[a] = hi[a] = dl[a];
     }
@@ -165,8 +166,9 @@ __device__ __forceinline__ ListTarget list_target(const Dev &d, uint32_t s)
 {
     ListTarget t;
     const int R = (int)d.R;
-    t.qx = d.p1x[s]; t.qy = d.p1y[s]; t.qz = d.p1z[s];
-    t.px = d.cur.x[s]; t.py = d.cur.y[s]; t.pz = d.cur.z[s];
+    const Pos3 pb = load_binned(d, s), pc = load_pos(d, d.cur, s);
+    t.qx = pb.x; t.qy = pb.y; t.qz = pb.z;
+    t.px = pc.x; t.py = pc.y; t.pz = pc.z;
     t.c0x = cell_coord(t.qx, d.Rm1, R); t.c0y = cell_coord(t.qy, d.Rm1, R); t.c0z = cell_coord(t.qz, d.Rm1, R);
     t.shx = cell_coord(t.px, d.Rm1, R) - t.c0x;                                  // :58
     t.shy = cell_coord(t.py, d.Rm1, R) - t.c0y;
@@ -193,6 +195,7 @@ __device__ __forceinline__ uint32_t shifted_mask(const ListTarget &t)
 }
 
 // The pair sums of VelPos.compute:67-98 from the recorded list of slot s (n entries), then :100-157.
+template <int PREC>
 __device__ __forceinline__ void walk_list_and_integrate(const Dev &d, uint32_t s, uint32_t n, uint32_t mask, bool live,
                                                         float pix, float piy, float piz)
 {
@@ -211,7 +214,7 @@ __device__ __forceinline__ void walk_list_and_integrate(const Dev &d, uint32_t s
     auto word = [&](uint32_t e) { return ent[(e < n ? e : n - 1) * kWave]; };    // one coalesced 256 B row per wave
     auto gather = [&](uint32_t w) {
         const uint32_t j = w & slot_mask;
-        const float4 pj = d.cur.p4[j];
+        const Pos3 pj = load_p4<PREC>(d, d.cur, j);
         const float4 rv = d.cur.rv[j];                                           // :86, :94
         return Cand{pj.x, pj.y, pj.z, rv.x, rv.y, rv.z, rv.w,
                     j != s && ((mask >> (w >> kNlSlotBits)) & 1u) != 0u};        // :82 and the stencil test :73
@@ -258,6 +261,7 @@ __device__ __forceinline__ void walk_list_and_integrate(const Dev &d, uint32_t s
 // (mean 17.8 entries, mean of the per-wave maxima 24.7: scripts/list_balance.py); dealing the slots of a workgroup to its
 // waves by list length cuts the trips by 19 % but ran 20-40 % SLOWER, stable or not (round 2): lanes that are no longer
 // spatial neighbours gather 64 unrelated cache lines per instruction.  Consecutive slots per wave stay.
+template <int PREC>
 __global__ void __launch_bounds__(kListBlock, SPH_LIST_MINWAVES) k_velpos_list(Dev d)
 {
     __shared__ uint32_t s_queue[2];
@@ -284,7 +288,7 @@ __global__ void __launch_bounds__(kListBlock, SPH_LIST_MINWAVES) k_velpos_list(D
     if (live && (t.c0z + t.shz < d.zt_lo || t.c0z + t.shz > d.zt_hi)) atomicAdd(&d.counters[kCntHaloViolation], 1ull);
     enqueue_block(d, hand_over, s, s_queue, d.queue2, kCntQueue2);
     if (!live) n = 0;
-    walk_list_and_integrate(d, s, n, t.mask, live, t.px, t.py, t.pz);
+    walk_list_and_integrate<PREC>(d, s, n, t.mask, live, t.px, t.py, t.pz);
     stat_add(d, kStatListed, live ? 1ull : 0ull);
     stat_add(d, kStatListEntries, (unsigned long long)n);
 }
@@ -312,7 +316,7 @@ __global__ void __launch_bounds__(kBlock) k_velpos_list_changers(Dev d)
                 if (recorded) continue;
                 const CellRange cr = cell_range(d, bx, by, bz);                  // bounds test :73 + the bucket row
                 for (uint32_t k = 0; k < cr.cnt; k++) {
-                    const float4 pj = d.cur.p4[cr.start + k];
+                    const Pos3 pj = load_p4(d, d.cur, cr.start + k);
                     const float rx = t.px - pj.x, ry = t.py - pj.y, rz = t.pz - pj.z;
                     if (__builtin_fmaf(rz, rz, __builtin_fmaf(ry, ry, rx * rx)) < d.h2_up) generic = true;   // superset of |r| < h
                 }
@@ -375,7 +379,8 @@ void launch_list_prepare(const Dev &d, hipStream_t s)
 void launch_velpos_lists(const Dev &d, hipStream_t s, hipEvent_t list_begin, hipEvent_t list_end)
 {
     if (list_begin) (void)hipEventRecord(list_begin, s);     // the events bracket k_velpos_list alone (bench.py roofline)
-    hipLaunchKernelGGL(k_velpos_list, dim3(cdiv(d.count, kListBlock)), dim3(kListBlock), 0, s, d);
+    if (d.prec == 0u) hipLaunchKernelGGL(k_velpos_list<0>, dim3(cdiv(d.count, kListBlock)), dim3(kListBlock), 0, s, d);
+    else hipLaunchKernelGGL(k_velpos_list<1>, dim3(cdiv(d.count, kListBlock)), dim3(kListBlock), 0, s, d);
     if (list_end) (void)hipEventRecord(list_end, s);
     if (d.nl_still) return;                        // first sub-step: nobody has changed cell, nothing was handed over
     const uint32_t g = cdiv(d.count, kBlock);

@@ -22,9 +22,10 @@ __global__ void __launch_bounds__(kBlock) k_mesh_properties(Dev d, MeshArgs a, f
     const uint32_t id = d.id[s];                                                      // :27
     const float4 rv = d.cur.rv[s];
     const float speed = sqrtf((rv.y * rv.y + rv.z * rv.z) + rv.w * rv.w);             // :32 length(vel.xyz)
-    const float w[3] = {d.cur.x[s] * a.sim_scale[0] - (a.sim_scale[0] * 0.5f),        // :41
-                        d.cur.y[s] * a.sim_scale[1] - (a.sim_scale[1] * 0.5f),
-                        d.cur.z[s] * a.sim_scale[2] - (a.sim_scale[2] * 0.5f)};
+    const Pos3 q = load_pos(d, d.cur, s);
+    const float w[3] = {q.x * a.sim_scale[0] - (a.sim_scale[0] * 0.5f),        // :41
+                        q.y * a.sim_scale[1] - (a.sim_scale[1] * 0.5f),
+                        q.z * a.sim_scale[2] - (a.sim_scale[2] * 0.5f)};
     // :44-60 mul(translation, scale) as the literal 4-term sums (0 * inf = NaN poisons a row like on any IEEE GPU)
     const float S[4][4] = {{a.scale[0], 0.f, 0.f, 0.f}, {0.f, a.scale[1], 0.f, 0.f}, {0.f, 0.f, a.scale[2], 0.f},
                            {0.f, 0.f, 0.f, 1.f}};

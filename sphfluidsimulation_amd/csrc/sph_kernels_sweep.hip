@@ -31,7 +31,8 @@ constexpr int kQueueGrid = 2048;      // blocks of the queue kernels (grid-strid
 template <bool RECORD>
 __device__ __forceinline__ uint32_t density_target(const Dev &d, uint32_t s)
 {
-    const float pix = d.cur.x[s], piy = d.cur.y[s], piz = d.cur.z[s];
+    const Pos3 pi = load_pos(d, d.cur, s);
+    const float pix = pi.x, piy = pi.y, piz = pi.z;
     const int R = (int)d.R;
     const int ix = cell_coord(pix, d.Rm1, R), iy = cell_coord(piy, d.Rm1, R), iz = cell_coord(piz, d.Rm1, R);
     float rho = 0.0f;
@@ -45,7 +46,8 @@ __device__ __forceinline__ uint32_t density_target(const Dev &d, uint32_t s)
                 const uint32_t code = (uint32_t)(((xo + 1) * 3 + (yo + 1)) * 3 + (zo + 1));
                 for (uint32_t k = 0; k < cr.cnt; k++) {
                     const uint32_t j = cr.start + k;
-                    const float rx = pix - d.cur.x[j], ry = piy - d.cur.y[j], rz = piz - d.cur.z[j];
+                    const Pos3 pj = load_pos(d, d.cur, j);
+                    const float rx = pix - pj.x, ry = piy - pj.y, rz = piz - pj.z;
                     const float r2 = (rx * rx + ry * ry) + rz * rz;              // Density.compute:24
                     rho += density_term_r2(d, r2);
                     if (RECORD && r2 < d.h2_list) {                              // superset of |r| < h + skin
@@ -73,7 +75,8 @@ __device__ __forceinline__ uint32_t density_target(const Dev &d, uint32_t s)
 
 __device__ __forceinline__ void velpos_target(const Dev &d, uint32_t s, bool live, uint16_t *list, uint32_t tid)
 {
-    const float pix = d.cur.x[s], piy = d.cur.y[s], piz = d.cur.z[s];            // :57
+    const Pos3 pi = load_pos(d, d.cur, s);
+    const float pix = pi.x, piy = pi.y, piz = pi.z;                              // :57
     const int R = (int)d.R;
     const int ix = cell_coord(pix, d.Rm1, R), iy = cell_coord(piy, d.Rm1, R), iz = cell_coord(piz, d.Rm1, R);
     const float4 rvi = d.cur.rv[s];
@@ -109,10 +112,11 @@ __device__ __forceinline__ void velpos_target(const Dev &d, uint32_t s, bool liv
                     const uint32_t j = cr.start + k;
                     float rx, ry, rz;
                     if (d.cur.p4) {                      // (wave-uniform) the packed copy: one 16-byte load instead of three
-                        const float4 pj = d.cur.p4[j];
+                        const Pos3 pj = load_p4(d, d.cur, j);
                         rx = pix - pj.x; ry = piy - pj.y; rz = piz - pj.z;
                     } else {
-                        rx = pix - d.cur.x[j]; ry = piy - d.cur.y[j]; rz = piz - d.cur.z[j];
+                        const Pos3 pj = load_pos(d, d.cur, j);
+                        rx = pix - pj.x; ry = piy - pj.y; rz = piz - pj.z;
                     }
                     const float r2 = (rx * rx + ry * ry) + rz * rz;
                     if (j != s && r2 < d.h2_up) {        // superset of |r| < h (VelPos.compute:37,43)

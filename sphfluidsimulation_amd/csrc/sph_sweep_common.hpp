@@ -158,13 +158,10 @@ __device__ __forceinline__ void pair_force(const Dev &d, uint32_t j, float pix, 
                                            float vix, float viy, float viz, float p_i, Force &f, bool literal)
 {
     const float4 rv = d.cur.rv[j];
-    pair_force_vals(d, pix - d.cur.x[j], piy - d.cur.y[j], piz - d.cur.z[j], rv.x, rv.y, rv.z, rv.w, vix, viy,
+    const Pos3 pj = load_pos(d, d.cur, j);
+    pair_force_vals(d, pix - pj.x, piy - pj.y, piz - pj.z, rv.x, rv.y, rv.z, rv.w, vix, viy,
                     viz, p_i, f, true, literal);                                 // :86-89
 }
-
-struct Pos3 {
-    float x, y, z;
-};
 
 // VelPos.compute:100-157: scaling, wall force, NaN guard, integrate, clamp, store.  Returns the new position.
 __device__ __forceinline__ Pos3 integrate_store(const Dev &d, uint32_t s, float pix, float piy, float piz,
@@ -213,10 +210,8 @@ __device__ __forceinline__ Pos3 integrate_store(const Dev &d, uint32_t s, float 
         vow = viw + 1.0f;
     }
     const Pos3 pn{clamp01(pix + dt * vox), clamp01(piy + dt * voy), clamp01(piz + dt * voz)};  // :153-154
-    d.nxt.x[s] = pn.x;
-    d.nxt.y[s] = pn.y;
-    d.nxt.z[s] = pn.z;
-    if (d.nxt.p4) d.nxt.p4[s] = make_float4(pn.x, pn.y, pn.z, 0.0f);
+    store_pos(d, d.nxt, s, pn);        // (precision 1: rounded to fp16 offsets from the slot's reference cell HERE, nowhere else)
+    if (d.nxt.p4) store_p4(d, d.nxt, s, pn);
     d.nxt.rv[s] = make_float4(rho_i, vox, voy, voz);                             // :156 (+ rho rides along)
     d.nxt.vw[s] = vow;
     if (is_wild(vox) || is_wild(voy) || is_wild(voz)) d.counters[kCntWildV0 + (d.wild_v_cur ^ 1)] = 1ull;

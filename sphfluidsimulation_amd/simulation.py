@@ -30,7 +30,7 @@ class SphFluidSimulation:
                  dampingCoefficient: float = 10.0, device_id: int = 0, profile: bool = False,
                  tiling: bool = True, lists: bool = True, graphs: bool = True, particleRadius: float = 0.01, lowSpeed: float = 0.0,
                  highSpeed: float = 0.5, substeps: int = 5, device_ids=None, halo_planes: int = 0, list_skin: float = 0.0,
-                 peer_copies: bool = False):
+                 peer_copies: bool = False, precision: int = 0):
         # inspector fields and defaults, SphFluidSimulation.cs:35-45
         self.preset = preset
         self.particleNumber = particleNumber
@@ -55,6 +55,7 @@ class SphFluidSimulation:
         self.device_ids = list(device_ids) if device_ids else None   # 2..8 ordinals: z-slabs on several GPUs of this process
         self.halo_planes = halo_planes  # ghost planes per slab face to start with (0 = 2)
         self.list_skin = list_skin      # neighbour-list skin / h (0 = 0.04)
+        self.precision = precision      # 1: positions stored as fp16 offsets from the cell centre (config C4)
         self.peer_copies = peer_copies  # multi-device: peer-to-peer copies instead of RCCL (SPH_FLAG_PEER_COPIES)
         self._ctx = C.c_void_p()
         self._derived = None
@@ -72,6 +73,7 @@ class SphFluidSimulation:
         p.damping_coeff = self.dampingCoefficient
         p.device_id = self.device_id
         p.substeps = int(self.substeps)
+        p.precision = int(self.precision)
         p.halo_planes = int(self.halo_planes)
         p.list_skin = float(self.list_skin)
         if self.device_ids:
