@@ -6,7 +6,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libsph_hip.so")
+LIB_PATH = os.environ.get("SPH_HIP_LIBRARY") or os.path.join(_HERE, "lib", "libsph_hip.so")   # (override: A/B runs of two builds)
 
 SPH_OK = 0
 SPH_E_INVALID_ARG = -1

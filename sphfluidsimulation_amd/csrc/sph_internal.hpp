@@ -205,37 +205,41 @@ __device__ __forceinline__ uint2 encode_pos(const Dev &d, Pos3 p, uint32_t ck)
     return make_uint2(float_to_half_bits(tx - sx - 0.5f) | float_to_half_bits(ty - sy - 0.5f) << 16,
                       float_to_half_bits(tz - sz - 0.5f) | sub << 16);
 }
+// PREC: 0 / 1 when the kernel is compiled per precision (k_velpos_list: a run-time test in its preamble and store cost 12 %),
+// -1 to test Dev::prec at run time (everything else: positions are touched once per particle there).
+template <int PREC = -1>
+__device__ __forceinline__ bool is_fp32(const Dev &d) { return PREC == 0 || (PREC < 0 && d.prec == 0u); }
+
+template <int PREC = -1>
 __device__ __forceinline__ Pos3 load_pos(const Dev &d, const Soa &a, uint32_t j)
 {
-    if (d.prec == 0u) return Pos3{a.x[j], a.y[j], a.z[j]};
+    if (is_fp32<PREC>(d)) return Pos3{a.x[j], a.y[j], a.z[j]};
     return decode_pos(d, a.h4[j], d.cellkey[j]);
 }
+template <int PREC = -1>
 __device__ __forceinline__ void store_pos(const Dev &d, const Soa &a, uint32_t s, Pos3 p)
 {
-    if (d.prec == 0u) {
+    if (is_fp32<PREC>(d)) {
         a.x[s] = p.x; a.y[s] = p.y; a.z[s] = p.z;
     } else {
         a.h4[s] = encode_pos(d, p, d.cellkey[s]);
     }
 }
-// the packed copy the neighbour-list kernels gather (Soa::p4): (x, y, z, -) fp32, or {offsets, reference cell} in precision 1
-template <int PREC>
+// the packed copy the neighbour-list kernels gather (Soa::p4): (x, y, z, -) fp32, or {record, reference cell} in precision 1
+template <int PREC = -1>
 __device__ __forceinline__ Pos3 load_p4(const Dev &d, const Soa &a, uint32_t j)
 {
-    if (PREC == 0) {
+    if (is_fp32<PREC>(d)) {
         const float4 q = a.p4[j];
         return Pos3{q.x, q.y, q.z};
     }
     const uint4 q = reinterpret_cast<const uint4 *>(a.p4)[j];
     return decode_pos(d, make_uint2(q.x, q.y), q.z);
 }
-__device__ __forceinline__ Pos3 load_p4(const Dev &d, const Soa &a, uint32_t j)
-{
-    return d.prec == 0u ? load_p4<0>(d, a, j) : load_p4<1>(d, a, j);
-}
+template <int PREC = -1>
 __device__ __forceinline__ void store_p4(const Dev &d, const Soa &a, uint32_t s, Pos3 p)
 {
-    if (d.prec == 0u) {
+    if (is_fp32<PREC>(d)) {
         a.p4[s] = make_float4(p.x, p.y, p.z, 0.0f);
     } else {
         const uint32_t ck = d.cellkey[s];
@@ -244,9 +248,10 @@ __device__ __forceinline__ void store_p4(const Dev &d, const Soa &a, uint32_t s,
     }
 }
 // where the particle of slot s was when it was binned (neighbour lists)
+template <int PREC = -1>
 __device__ __forceinline__ Pos3 load_binned(const Dev &d, uint32_t s)
 {
-    if (d.prec == 0u) return Pos3{d.p1x[s], d.p1y[s], d.p1z[s]};
+    if (is_fp32<PREC>(d)) return Pos3{d.p1x[s], d.p1y[s], d.p1z[s]};
     return decode_pos(d, d.p1h[s], d.cellkey[s]);
 }
 

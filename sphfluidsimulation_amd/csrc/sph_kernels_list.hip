@@ -162,11 +162,12 @@ struct ListTarget {
     uint32_t mask;         // recorded stencil cells (0..26) that are still in the stencil
 };
 
+template <int PREC = -1>
 __device__ __forceinline__ ListTarget list_target(const Dev &d, uint32_t s)
 {
     ListTarget t;
     const int R = (int)d.R;
-    const Pos3 pb = load_binned(d, s), pc = load_pos(d, d.cur, s);
+    const Pos3 pb = load_binned<PREC>(d, s), pc = load_pos<PREC>(d, d.cur, s);
     t.qx = pb.x; t.qy = pb.y; t.qz = pb.z;
     t.px = pc.x; t.py = pc.y; t.pz = pc.z;
     t.c0x = cell_coord(t.qx, d.Rm1, R); t.c0y = cell_coord(t.qy, d.Rm1, R); t.c0z = cell_coord(t.qz, d.Rm1, R);
@@ -249,7 +250,7 @@ __device__ __forceinline__ void walk_list_and_integrate(const Dev &d, uint32_t s
             a1 = b1;
         }
     }
-    if (live) integrate_store(d, s, pix, piy, piz, vix, viy, viz, viw, rho_i, f);  // :100-157
+    if (live) integrate_store<PREC>(d, s, pix, piy, piz, vix, viy, viz, viw, rho_i, f);  // :100-157
 }
 
 // VelPos.compute:46-158 for the targets of CALM bricks, one lane per slot: pair sums from the list recorded by the
@@ -269,7 +270,7 @@ __global__ void __launch_bounds__(kListBlock, SPH_LIST_MINWAVES) k_velpos_list(D
     const uint32_t s_raw = xcd_contiguous_block() * kListBlock + threadIdx.x;
     bool live = s_raw < d.count;
     const uint32_t s = live ? s_raw : 0u;
-    ListTarget t = list_target(d, s);
+    ListTarget t = list_target<PREC>(d, s);
     uint32_t n = d.nl_cnt[s];
     const uint32_t key = bucket_key(d, t.qx, t.qy, t.qz);                        // the bin, Bucket.compute:26-29
     live = live && key < d.num_cells;                                            // limbo: queued by the brick kernel

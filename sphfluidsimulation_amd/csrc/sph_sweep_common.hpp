@@ -164,6 +164,7 @@ __device__ __forceinline__ void pair_force(const Dev &d, uint32_t j, float pix, 
 }
 
 // VelPos.compute:100-157: scaling, wall force, NaN guard, integrate, clamp, store.  Returns the new position.
+template <int PREC = -1>
 __device__ __forceinline__ Pos3 integrate_store(const Dev &d, uint32_t s, float pix, float piy, float piz,
                                                 float vix, float viy, float viz, float viw, float rho_i,
                                                 Force f)
@@ -210,8 +211,8 @@ __device__ __forceinline__ Pos3 integrate_store(const Dev &d, uint32_t s, float 
         vow = viw + 1.0f;
     }
     const Pos3 pn{clamp01(pix + dt * vox), clamp01(piy + dt * voy), clamp01(piz + dt * voz)};  // :153-154
-    store_pos(d, d.nxt, s, pn);        // (precision 1: rounded to fp16 offsets from the slot's reference cell HERE, nowhere else)
-    if (d.nxt.p4) store_p4(d, d.nxt, s, pn);
+    store_pos<PREC>(d, d.nxt, s, pn);  // (precision 1: rounded to the fp16 record of the slot's reference cell HERE, nowhere else)
+    if (d.nxt.p4) store_p4<PREC>(d, d.nxt, s, pn);
     d.nxt.rv[s] = make_float4(rho_i, vox, voy, voz);                             // :156 (+ rho rides along)
     d.nxt.vw[s] = vow;
     if (is_wild(vox) || is_wild(voy) || is_wild(voz)) d.counters[kCntWildV0 + (d.wild_v_cur ^ 1)] = 1ull;

@@ -195,25 +195,29 @@ class SlabSimulation:
         if self.world == 1:
             self.transport = "none"
             return
-        ok = 0.0
         if want in ("rccl", "auto"):
-            try:
-                ident = C.create_string_buffer(N.SPH_COMM_ID_BYTES)
-                if self.rank == 0:
-                    N.check(L.sph_comm_unique_id(ident))
+            # Three collective steps, each entered by EVERY rank whatever happened before (a rank that skipped one would
+            # leave the others waiting): (1) can every rank load RCCL and make an id?  (2) rank 0's id to all;
+            # (3) ncclCommInitRank, then: did every rank succeed?
+            ident = C.create_string_buffer(N.SPH_COMM_ID_BYTES)
+            have = 1.0 if L.sph_comm_unique_id(ident) == N.SPH_OK else 0.0
+            if have == 0.0:
+                print(f"rank {self.rank}: RCCL unavailable ({L.sph_last_error(None).decode()})", flush=True)
+            ok = 0.0
+            if self.control.all_reduce(have, "min") >= 1.0:
                 raw = self.control.broadcast_bytes(ident.raw if self.rank == 0 else None, N.SPH_COMM_ID_BYTES)
                 ident = C.create_string_buffer(raw, N.SPH_COMM_ID_BYTES)
-                self._check(L.sph_slab_comm_init(self._ctx, ident))
-                ok = 1.0
-            except N.SphError as e:
-                if want == "rccl":
-                    raise
-                print(f"rank {self.rank}: RCCL transport unavailable ({e}); falling back to the host transport", flush=True)
-            if self.control.all_reduce(ok, "min") >= 1.0:
-                self.transport = "rccl"
-                return
+                rc = L.sph_slab_comm_init(self._ctx, ident)
+                ok = 1.0 if rc == N.SPH_OK else 0.0
+                if ok == 0.0:
+                    print(f"rank {self.rank}: ncclCommInitRank failed ({L.sph_last_error(self._ctx).decode()})", flush=True)
+                if self.control.all_reduce(ok, "min") >= 1.0:
+                    self.transport = "rccl"
+                    return
             if want == "rccl":
                 raise RuntimeError("RCCL transport could not be set up on every rank")
+            if self.rank == 0:
+                print("falling back to the host transport (gloo) on every rank", flush=True)
         self.host_exchange = HostExchange(self.rank, self.world, self.group)
         self._check(L.sph_slab_set_host_transport(self._ctx, self.host_exchange.exchange_cb, self.host_exchange.allreduce_cb, None))
         self.transport = "host"
