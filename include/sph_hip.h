@@ -197,6 +197,22 @@ int sph_mesh_properties_device_ptr(SphContext *ctx, void **device_ptr, size_t *b
  * sees no device at all and faults -- the cause of round 1's crash (profiles/r02_fd_import_two_runtime_images.txt). */
 int sph_export_mesh_properties_fd(SphContext *ctx, int *fd, size_t *bytes);
 
+/* Row f4, second step: the Read textures themselves without a host round trip.  sph_update_state_textures fills the library's
+ * position / velocity / density staging textures (float4 / float4 / float per texel, id = y*res + x: exactly what
+ * SphFluidSimulation.cs:141-153 allocates as _particlePositionTextures[Read] ...) ON THE DEVICE from the current state;
+ * sph_export_state_fd hands one of them out as a dma-buf fd (import once, VK_KHR_external_memory_fd; same rules as
+ * sph_export_mesh_properties_fd).  Ordering across the APIs: either sph_synchronize before the renderer reads, or give the
+ * library a semaphore the renderer created -- sph_import_semaphore_fd (VK_KHR_external_semaphore_fd: binary, or timeline = 1)
+ * -- and sph_signal_semaphore(value) enqueues its signal on the context's stream behind everything issued so far.
+ * (The semaphore path cannot be exercised in this image: nothing here creates an exportable semaphore.) */
+#define SPH_STATE_POSITION 0
+#define SPH_STATE_VELOCITY 1
+#define SPH_STATE_DENSITY 2
+int sph_update_state_textures(SphContext *ctx);
+int sph_export_state_fd(SphContext *ctx, int which, int *fd, size_t *bytes);
+int sph_import_semaphore_fd(SphContext *ctx, int fd, int timeline);
+int sph_signal_semaphore(SphContext *ctx, uint64_t value);
+
 /* One Update() (SphFluidSimulation.cs:96-102) with Time.deltaTime = delta_time:
  * BucketGeneration, DensityCalculation, substeps x UpdateVelocityAndPosition(delta_time/25). */
 int sph_step(SphContext *ctx, float delta_time);

@@ -85,6 +85,11 @@ public static class SphNative
     [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int sph_mesh_properties_device_ptr(IntPtr ctx, out IntPtr devicePtr, out UIntPtr bytes);
     // row f4: dma-buf fd of the render-feed buffer for VK_KHR_external_memory_fd (the caller closes the fd)
     [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int sph_export_mesh_properties_fd(IntPtr ctx, out int fd, out UIntPtr bytes);
+    // row f4, second step: the Read textures on the device (no sph_download + SetPixelData): which = 0 position, 1 velocity, 2 density
+    [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int sph_update_state_textures(IntPtr ctx);
+    [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int sph_export_state_fd(IntPtr ctx, int which, out int fd, out UIntPtr bytes);
+    [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int sph_import_semaphore_fd(IntPtr ctx, int fd, int timeline);
+    [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int sph_signal_semaphore(IntPtr ctx, ulong value);
     [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int sph_download(IntPtr ctx, float[] pos4, float[] vel4, float[] rho);
     [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int sph_step(IntPtr ctx, float deltaTime);
     [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int sph_step_n(IntPtr ctx, float deltaTime, int frames);

@@ -497,6 +497,9 @@ const uint32_t *oracle_sim_bucket(const OracleSim *s) { return s->bucket; }
  * Same floating-point contract as above.  The one transcendental, pow(count/fill, 1/3) at
  * InitParticles.compute:20,53,86, is evaluated by the CALLER (float powf) and passed in as
  * particle_per_dim, so oracle and engine cannot disagree on it.
+ * The noise is the algorithm of webgl-noise (https://github.com/ashima/webgl-noise), Copyright (C) 2011 by Ashima Arts
+ * (Simplex noise) and Stefan Gustavson (Classic noise), MIT License, in Lex-DRL's CgFx/HLSL port; the full upstream
+ * notice is reproduced in sphfluidsimulation_amd/csrc/sph_kernels_init.hip.
  * ====================================================================================== */
 
 typedef struct { float x, y, z, w; } f4;

@@ -158,6 +158,10 @@ SYMBOLS = {
     "sph_download_mesh_properties": (C.c_int, [_CTX, _FP]),
     "sph_mesh_properties_device_ptr": (C.c_int, [_CTX, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
     "sph_export_mesh_properties_fd": (C.c_int, [_CTX, C.POINTER(C.c_int), C.POINTER(C.c_size_t)]),
+    "sph_update_state_textures": (C.c_int, [_CTX]),
+    "sph_export_state_fd": (C.c_int, [_CTX, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_size_t)]),
+    "sph_import_semaphore_fd": (C.c_int, [_CTX, C.c_int, C.c_int]),
+    "sph_signal_semaphore": (C.c_int, [_CTX, C.c_uint64]),
     "sph_step": (C.c_int, [_CTX, C.c_float]),
     "sph_step_n": (C.c_int, [_CTX, C.c_float, C.c_int]),
     "sph_bucket_generation": (C.c_int, [_CTX]),

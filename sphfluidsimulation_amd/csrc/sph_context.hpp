@@ -81,6 +81,14 @@ struct SphContext {
     hipMemGenericAllocationHandle_t mesh_handle{};
     void *mesh_va = nullptr;
     size_t mesh_va_size = 0;
+    // ... and the staging textures (position, velocity, density in the reference's texture layout), once asked for
+    struct ExportBuf {
+        hipMemGenericAllocationHandle_t handle{};
+        void *va = nullptr;
+        size_t size = 0;
+    } state_export[3];
+    hipExternalSemaphore_t ext_sem = nullptr;   // a renderer's semaphore, signalled on the stream (sph_import_semaphore_fd)
+    bool ext_sem_timeline = false;
     bool uploaded = false, grid_valid = false;
     int substeps_since_upload = 0;
     float dt_last = 0.0f;

@@ -505,6 +505,13 @@ int sph_destroy(SphContext *c)
         (void)hipMemAddressFree(c->mesh_va, c->mesh_va_size);
         (void)hipMemRelease(c->mesh_handle);
     }
+    for (auto &e : c->state_export)
+        if (e.va) {
+            (void)hipMemUnmap(e.va, e.size);
+            (void)hipMemAddressFree(e.va, e.size);
+            (void)hipMemRelease(e.handle);
+        }
+    if (c->ext_sem) (void)hipDestroyExternalSemaphore(c->ext_sem);
     if (c->owns_group && c->group) slab_group_destroy(c->group);
     slab_rank_destroy(c);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -676,6 +683,116 @@ int sph_export_mesh_properties_fd(SphContext *c, int *fd, size_t *bytes)
     }
     *fd = out;
     if (bytes) *bytes = c->mesh_va_size;
+    return SPH_OK;
+}
+
+// An exportable (dma-buf) device allocation of at least `bytes`, mapped read-write on the context's device.
+static int make_exportable(SphContext *c, size_t bytes, hipMemGenericAllocationHandle_t *handle, void **va_out, size_t *size_out)
+{
+    hipMemAllocationProp prop{};
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = c->device;
+    prop.requestedHandleTypes = hipMemHandleTypePosixFileDescriptor;
+    size_t gran = 0;
+    if (hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityMinimum) != hipSuccess || gran == 0) {
+        (void)hipGetLastError();
+        return fail(c, SPH_E_UNSUPPORTED, "this device / driver has no exportable (virtual-memory) allocations");
+    }
+    const size_t size = (bytes + gran - 1) / gran * gran;
+    hipMemGenericAllocationHandle_t h{};
+    void *va = nullptr;
+    if (hipMemCreate(&h, size, &prop, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(c, SPH_E_UNSUPPORTED, "hipMemCreate of an exportable allocation failed");
+    }
+    hipMemAccessDesc acc{};
+    acc.location.type = hipMemLocationTypeDevice;
+    acc.location.id = c->device;
+    acc.flags = hipMemAccessFlagsProtReadWrite;
+    if (hipMemAddressReserve(&va, size, 0, nullptr, 0) != hipSuccess || hipMemMap(va, size, 0, h, 0) != hipSuccess ||
+        hipMemSetAccess(va, size, &acc, 1) != hipSuccess) {
+        (void)hipGetLastError();
+        if (va) (void)hipMemAddressFree(va, size);
+        (void)hipMemRelease(h);
+        return fail(c, SPH_E_HIP, "mapping the exportable allocation failed");
+    }
+    *handle = h;
+    *va_out = va;
+    *size_out = size;
+    return SPH_OK;
+}
+
+int sph_update_state_textures(SphContext *c)
+{
+    if (!c) return fail(nullptr, SPH_E_INVALID_ARG, "ctx is NULL");
+    if (c->is_group || c->slab) return fail(c, SPH_E_UNSUPPORTED, "sph_update_state_textures: single-device contexts only");
+    if (!c->uploaded) return fail(c, SPH_E_BAD_STATE, "sph_update_state_textures before sph_upload");
+    HIP_TRY(c, hipSetDevice(c->device));
+    launch_download_merge(c->dev, c->pw0, c->substeps_since_upload, c->dt_last, c->pos4_dev, c->vel4_dev, c->rho_id_dev, c->stream);
+    HIP_TRY(c, hipGetLastError());
+    return SPH_OK;
+}
+
+int sph_export_state_fd(SphContext *c, int which, int *fd, size_t *bytes)
+{
+    if (!c) return fail(nullptr, SPH_E_INVALID_ARG, "ctx is NULL");
+    if (!fd || which < 0 || which > 2) return fail(c, SPH_E_INVALID_ARG, "fd is NULL or texture %d not in [0,2]", which);
+    if (c->is_group || c->slab) return fail(c, SPH_E_UNSUPPORTED, "sph_export_state_fd: single-device contexts only");
+    HIP_TRY(c, hipSetDevice(c->device));
+    SphContext::ExportBuf &e = c->state_export[which];
+    const size_t used = (size_t)c->dev.count * (which == SPH_STATE_DENSITY ? sizeof(float) : sizeof(float4));
+    if (!e.va) {
+        int rc = make_exportable(c, used, &e.handle, &e.va, &e.size);
+        if (rc != SPH_OK) return rc;
+        // the staging texture moves there (the hipMalloc'ed one stays in c->allocs until sph_destroy)
+        void *old = which == SPH_STATE_POSITION ? (void *)c->pos4_dev : which == SPH_STATE_VELOCITY ? (void *)c->vel4_dev : (void *)c->rho_id_dev;
+        HIP_TRY(c, hipMemcpyAsync(e.va, old, used, hipMemcpyDeviceToDevice, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        if (which == SPH_STATE_POSITION) c->pos4_dev = (float4 *)e.va;
+        else if (which == SPH_STATE_VELOCITY) c->vel4_dev = (float4 *)e.va;
+        else c->rho_id_dev = (float *)e.va;
+    }
+    int out = -1;
+    if (hipMemExportToShareableHandle(&out, e.handle, hipMemHandleTypePosixFileDescriptor, 0) != hipSuccess || out < 0) {
+        (void)hipGetLastError();
+        return fail(c, SPH_E_UNSUPPORTED, "hipMemExportToShareableHandle failed: no dma-buf export on this system");
+    }
+    *fd = out;
+    if (bytes) *bytes = e.size;
+    return SPH_OK;
+}
+
+int sph_import_semaphore_fd(SphContext *c, int fd, int timeline)
+{
+    if (!c) return fail(nullptr, SPH_E_INVALID_ARG, "ctx is NULL");
+    if (fd < 0) return fail(c, SPH_E_INVALID_ARG, "fd %d", fd);
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (c->ext_sem) {
+        (void)hipDestroyExternalSemaphore(c->ext_sem);
+        c->ext_sem = nullptr;
+    }
+    hipExternalSemaphoreHandleDesc desc{};
+    desc.type = timeline ? hipExternalSemaphoreHandleTypeTimelineSemaphoreFd : hipExternalSemaphoreHandleTypeOpaqueFd;
+    desc.handle.fd = fd;
+    hipExternalSemaphore_t sem = nullptr;
+    if (hipImportExternalSemaphore(&sem, &desc) != hipSuccess || !sem) {
+        (void)hipGetLastError();
+        return fail(c, SPH_E_UNSUPPORTED, "hipImportExternalSemaphore failed: not a %s semaphore fd of this GPU", timeline ? "timeline" : "binary");
+    }
+    c->ext_sem = sem;
+    c->ext_sem_timeline = timeline != 0;
+    return SPH_OK;
+}
+
+int sph_signal_semaphore(SphContext *c, uint64_t value)
+{
+    if (!c) return fail(nullptr, SPH_E_INVALID_ARG, "ctx is NULL");
+    if (!c->ext_sem) return fail(c, SPH_E_BAD_STATE, "sph_signal_semaphore before sph_import_semaphore_fd");
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipExternalSemaphoreSignalParams p{};
+    p.params.fence.value = value;
+    HIP_TRY(c, hipSignalExternalSemaphoresAsync(&c->ext_sem, &p, 1, c->stream));
     return SPH_OK;
 }
 

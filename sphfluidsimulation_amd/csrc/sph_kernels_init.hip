@@ -5,6 +5,21 @@
 // One IEEE fp32 operation per source operation (-ffp-contract=off), so the positions are bit-identical
 // to oracle/sph_oracle.c::oracle_init_particles.  The one transcendental, pow(count/fill, 1/3) at
 // InitParticles.compute:20,53,86, is evaluated on the host (powf) and arrives as particle_per_dim.
+//
+// The 4-D simplex noise restated below (mod289, permute, taylorInvSqrt, grad4, snoise) is the algorithm of
+// "webgl-noise" by Ashima Arts / Stefan Gustavson (https://github.com/ashima/webgl-noise), in the CgFx/HLSL port by
+// Lex-DRL that the reference vendors as noiseSimplex.cginc.  Upstream notice, as that file carries it (MIT License):
+//   Copyright (C) 2011 by Ashima Arts (Simplex noise)
+//   Copyright (C) 2011 by Stefan Gustavson (Classic noise)
+//   Permission is hereby granted, free of charge, to any person obtaining a copy of this software and associated
+//   documentation files (the "Software"), to deal in the Software without restriction, including without limitation the
+//   rights to use, copy, modify, merge, publish, distribute, sublicense, and/or sell copies of the Software, and to permit
+//   persons to whom the Software is furnished to do so, subject to the following conditions: The above copyright notice and
+//   this permission notice shall be included in all copies or substantial portions of the Software.
+//   THE SOFTWARE IS PROVIDED "AS IS", WITHOUT WARRANTY OF ANY KIND, EXPRESS OR IMPLIED, INCLUDING BUT NOT LIMITED TO THE
+//   WARRANTIES OF MERCHANTABILITY, FITNESS FOR A PARTICULAR PURPOSE AND NONINFRINGEMENT.  IN NO EVENT SHALL THE AUTHORS OR
+//   COPYRIGHT HOLDERS BE LIABLE FOR ANY CLAIM, DAMAGES OR OTHER LIABILITY, WHETHER IN AN ACTION OF CONTRACT, TORT OR
+//   OTHERWISE, ARISING FROM, OUT OF OR IN CONNECTION WITH THE SOFTWARE OR THE USE OR OTHER DEALINGS IN THE SOFTWARE.
 #include "sph_internal.hpp"
 
 namespace sph {

@@ -216,3 +216,59 @@ def test_gpu_mesh_properties_same_process_import():
     for phase in ("before", "after"):
         assert sums[phase][:2] == sums[phase][2:], (phase, sums)   # the import sees what the library wrote, also after an update
     assert sums["before"] != sums["after"]
+
+
+@pytest.mark.gpu
+def test_gpu_state_textures_zero_copy_export():
+    """Row f4, second step: the position / velocity / density textures (reference layout, SphFluidSimulation.cs:141-153) filled
+    on the device and handed out as dma-buf fds; a child process imports them (as a renderer would) and sees what sph_download
+    returns, also after a later update.  The semaphore entry points fail cleanly on something that is not a semaphore."""
+    import ctypes as C
+    import os
+    import subprocess
+    import sys
+    from sphfluidsimulation_amd.simulation import SphFluidSimulation
+    from sphfluidsimulation_amd import _native as N
+    n = 16384
+    pos0, vel0 = presets.dam_break(n, 0.8, seed=8, jitter=0.3)
+    sim = SphFluidSimulation(particleNumber=n, bucketResolution=19, damFillRate=0.8).Start(pos0, vel0)
+    child = os.path.join(os.path.dirname(os.path.abspath(__file__)), "import_fd_child.py")
+    L = N.lib()
+
+    def checksum(a):
+        u = _bits(np.ascontiguousarray(a)).reshape(-1)
+        return int(u.astype(np.uint64).sum()), int(np.bitwise_xor.reduce(u))
+
+    def seen_by_child(fd, size, nbytes):
+        sim.synchronize()
+        env = {k: v for k, v in os.environ.items() if k != "PYTHONPATH"}
+        r = subprocess.run([sys.executable, child, str(fd), str(size), str(nbytes)], pass_fds=(fd,), env=env,
+                           capture_output=True, text=True, timeout=300)
+        line = [l for l in r.stdout.splitlines() if l.startswith(("CHECKSUM", "FAIL"))]
+        assert r.returncode == 0 and line and line[0].startswith("CHECKSUM"), (r.returncode, r.stdout[-500:], r.stderr[-500:])
+        return tuple(int(x) for x in line[0].split()[1:])
+
+    try:
+        sim.Update(1 / 600)
+        fds = []
+        for which, nbytes in ((0, n * 16), (1, n * 16), (2, n * 4)):
+            fd, size = C.c_int(-1), C.c_size_t(0)
+            rc = L.sph_export_state_fd(sim._ctx, which, C.byref(fd), C.byref(size))
+            if rc == N.SPH_E_UNSUPPORTED:
+                pytest.skip("no exportable device memory on this system: " + L.sph_last_error(sim._ctx).decode())
+            assert rc == 0 and fd.value >= 0 and size.value >= nbytes
+            fds.append((fd.value, size.value, nbytes))
+        for frame in range(2):
+            N.check(L.sph_update_state_textures(sim._ctx), sim._ctx)
+            want = sim.download()
+            for (fd, size, nbytes), arr in zip(fds, want):
+                assert seen_by_child(fd, size, nbytes) == checksum(arr), f"texture differs from sph_download (frame {frame})"
+            sim.Update(1 / 600)
+        assert L.sph_signal_semaphore(sim._ctx, 1) == N.SPH_E_BAD_STATE
+        r, w = os.pipe()
+        assert L.sph_import_semaphore_fd(sim._ctx, r, 0) in (N.SPH_E_UNSUPPORTED, N.SPH_E_HIP)   # a pipe is no semaphore: refused, no crash
+        os.close(r); os.close(w)
+        for fd, _, _ in fds:
+            os.close(fd)
+    finally:
+        sim.OnDestroy()
