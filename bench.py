@@ -89,7 +89,8 @@ def cpu_baseline(n, R, fill, pos0, vel0, dt_frame):
                 sample=f"{CPU_FRAMES} frames (grid + density + 5 sub-steps each) of the same {n}-particle dam-break, "
                        f"{dt:.2f} s wall, OpenMP {threads} threads, gcc -O2 -ffp-contract=off")
     other = {}
-    for name, nn, frames, thr in (("C0_4096_all_threads", 4096, 20, threads), ("C1_262144_all_threads", 262144, 5, threads),
+    # (the small boxes on as many threads as they can feed: 256 OpenMP threads on 4 096 particles only wait for each other)
+    for name, nn, frames, thr in (("C0_4096", 4096, 20, min(threads, 4)), ("C1_262144", 262144, 5, min(threads, 32)),
                                   ("C1_262144_1_thread", 262144, 1, 1)):
         RR = presets.scene_bucket_resolution(nn)
         p0, v0 = presets.dam_break(nn, fill, 1)
@@ -107,7 +108,8 @@ def committed_csv(suffix, kernel_substr):
     if not files:
         return None, None
     for row in csv.DictReader(open(files[-1])):
-        if kernel_substr in row["kernel"]:
+        name = row["kernel"]
+        if kernel_substr + "<" in name or kernel_substr + "(" in name:      # (k_velpos_list, not k_velpos_list_changers)
             return row, os.path.relpath(files[-1], ROOT) + " (16 777 216 particles)"
     return None, None
 

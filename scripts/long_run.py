@@ -7,9 +7,10 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 16777216
 frames = int(sys.argv[2]) if len(sys.argv) > 2 else 200
 chunk = int(sys.argv[3]) if len(sys.argv) > 3 else 20
 lists = (sys.argv[4] != "nolists") if len(sys.argv) > 4 else True
+precision = int(sys.argv[5]) if len(sys.argv) > 5 else 0
 R = presets.scene_bucket_resolution(n)
 pos0, vel0 = presets.dam_break(n, 0.8, 1)
-sim = SphFluidSimulation(particleNumber=n, bucketResolution=R, damFillRate=0.8, profile=True, lists=lists).Start(pos0, vel0)
+sim = SphFluidSimulation(particleNumber=n, bucketResolution=R, damFillRate=0.8, profile=True, lists=lists, precision=precision).Start(pos0, vel0)
 dt = presets.bench_dt_frame(R)
 for f0 in range(0, frames, chunk):
     sim.reset_stats()
