@@ -295,34 +295,42 @@ __global__ void __launch_bounds__(kListBlock, SPH_LIST_MINWAVES) k_velpos_list(D
 }
 
 // The targets of k_velpos_list that changed cell since the lists were recorded: a bin that ENTERED their stencil might
-// hold a candidate within h.  One lane per such target looks (distance pre-test on the listed particles of those <= 19
-// bins); if it finds one, or if the target is more than one cell from its bin (k_velpos_list did not integrate it), the
-// generic scanning kernel takes the target -- and overwrites what k_velpos_list stored for it.
+// hold a candidate within h.  HALF A WAVE per such target, one lane per bin of its current stencil (27 of 32 lanes; one lane
+// per target walked its <= 19 new bins one dependent gather at a time: 0.135 ms for 1 % of the targets): distance pre-test
+// on the listed particles of the bins that are not in the recorded stencil.  If any lane finds one, or if the target is more
+// than one cell from its bin (k_velpos_list did not integrate it), the generic scanning kernel takes the target -- and
+// overwrites what k_velpos_list stored for it.
 __global__ void __launch_bounds__(kBlock) k_velpos_list_changers(Dev d)
 {
     const uint32_t qlen = (uint32_t)d.counters[kCntQueue2];
-    for (uint32_t q0 = blockIdx.x * kBlock; q0 < qlen; q0 += gridDim.x * kBlock) {   // block-uniform
-        const uint32_t q = q0 + threadIdx.x;
+    constexpr uint32_t kPerBlock = kBlock / 32;          // targets per workgroup per trip
+    const uint32_t half = threadIdx.x / 32u, code = threadIdx.x & 31u;
+    for (uint32_t q0 = blockIdx.x * kPerBlock; q0 < qlen; q0 += gridDim.x * kPerBlock) {   // block-uniform
+        const uint32_t q = q0 + half;
         const bool live = q < qlen;
         const uint32_t s = d.queue2[live ? q : qlen - 1];
         const ListTarget t = list_target(d, s);
-        bool generic = live && !one_cell_away(t);
-        if (live && !generic) {
-            // bins of the current stencil that are not in the recorded one: beyond c0 +- 1 on an axis that moved
+        const bool far = !one_cell_away(t);
+        bool hit = false;
+        if (live && !far && code < 27u) {
+            // the bin of this lane; only those beyond c0 +- 1 on an axis that moved were not recorded
             const int cx = t.c0x + t.shx, cy = t.c0y + t.shy, cz = t.c0z + t.shz;
-            for (int code = 0; code < 27 && !generic; code++) {
-                const int bx = cx + code / 9 - 1, by = cy + (code / 3) % 3 - 1, bz = cz + code % 3 - 1;
-                const bool recorded = bx >= t.c0x - 1 && bx <= t.c0x + 1 && by >= t.c0y - 1 && by <= t.c0y + 1 &&
-                                      bz >= t.c0z - 1 && bz <= t.c0z + 1;
-                if (recorded) continue;
+            const int bx = cx + (int)code / 9 - 1, by = cy + ((int)code / 3) % 3 - 1, bz = cz + (int)code % 3 - 1;
+            const bool recorded = bx >= t.c0x - 1 && bx <= t.c0x + 1 && by >= t.c0y - 1 && by <= t.c0y + 1 &&
+                                  bz >= t.c0z - 1 && bz <= t.c0z + 1;
+            if (!recorded) {
                 const CellRange cr = cell_range(d, bx, by, bz);                  // bounds test :73 + the bucket row
                 for (uint32_t k = 0; k < cr.cnt; k++) {
                     const Pos3 pj = load_p4(d, d.cur, cr.start + k);
                     const float rx = t.px - pj.x, ry = t.py - pj.y, rz = t.pz - pj.z;
-                    if (__builtin_fmaf(rz, rz, __builtin_fmaf(ry, ry, rx * rx)) < d.h2_up) generic = true;   // superset of |r| < h
+                    if (__builtin_fmaf(rz, rz, __builtin_fmaf(ry, ry, rx * rx)) < d.h2_up) hit = true;   // superset of |r| < h
                 }
             }
         }
+        // per half-wave: does the target go to the generic kernel?  lane 0 of the half speaks for it
+        const unsigned long long hits = __ballot(hit);
+        const unsigned long long mine = (hits >> (32u * (half & 1u))) & 0xFFFFFFFFull;
+        const bool generic = live && code == 0u && (far || mine != 0ull);
         const unsigned long long m = __ballot(generic);                          // (wave-aggregated: this is rare)
         if (m) {
             const int lane = threadIdx.x & (kWave - 1), leader = __ffsll((long long)m) - 1;
@@ -385,7 +393,7 @@ void launch_velpos_lists(const Dev &d, hipStream_t s, hipEvent_t list_begin, hip
     if (list_end) (void)hipEventRecord(list_end, s);
     if (d.nl_still) return;                        // first sub-step: nobody has changed cell, nothing was handed over
     const uint32_t g = cdiv(d.count, kBlock);
-    hipLaunchKernelGGL(k_velpos_list_changers, dim3(g < 1024u ? g : 1024u), dim3(kBlock), 0, s, d);
+    hipLaunchKernelGGL(k_velpos_list_changers, dim3(g < 4096u ? g : 4096u), dim3(kBlock), 0, s, d);
 }
 
 }  // namespace sph

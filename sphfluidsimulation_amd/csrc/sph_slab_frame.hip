@@ -440,6 +440,7 @@ int slab_configure(SphContext *c, int rank, int world)
     if ((rc = ralloc(c, &r->snap_x, n)) != SPH_OK || (rc = ralloc(c, &r->snap_y, n)) != SPH_OK || (rc = ralloc(c, &r->snap_z, n)) != SPH_OK ||
         (rc = ralloc(c, &r->snap_vw, n)) != SPH_OK || (rc = ralloc(c, &r->snap_rv, n)) != SPH_OK || (rc = ralloc(c, &r->snap_id, n)) != SPH_OK)
         return rc;
+    HIP_TRY(c, hipMemset(r->counters, 0, kSlabCounterCount * sizeof(uint32_t)));   // (kSlabMisplaced accumulates from here on)
     HIP_TRY(c, hipMemset(r->hdr_send, 0, 8 * sizeof(uint32_t)));
     HIP_TRY(c, hipMemset(r->hdr_recv, 0, 8 * sizeof(uint32_t)));
     HIP_TRY(c, hipMemset(r->viol_dev, 0, sizeof(unsigned long long)));
