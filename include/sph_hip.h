@@ -88,6 +88,8 @@ typedef struct SphParams {
 #define SPH_FLAG_NO_LISTS 4u    /* diagnostic: every sub-step re-scans its 27 bins (no frame-coherent neighbour lists) */
 #define SPH_FLAG_LISTS_ALWAYS 16u /* diagnostic: record neighbour lists every frame (default: only while they pay, see
                                     SphStats.frames_without_lists) */
+#define SPH_FLAG_NO_OVERLAP 64u  /* z-slab mode, diagnostic: refresh the ghosts after the whole sub-step instead of behind its boundary pass */
+#define SPH_FLAG_FORCE_TWO_PASS 128u /* z-slab mode, diagnostic: two-pass sub-steps even with one slab (measures what the second pass costs) */
 #define SPH_FLAG_PEER_COPIES 32u /* multi-device context: move the halo with peer-to-peer device copies instead of RCCL */
 #define SPH_FLAG_NO_GRAPHS 8u   /* diagnostic: sph_step issues its ~60 launches every frame instead of replaying a HIP graph */
 

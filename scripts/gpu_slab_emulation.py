@@ -9,8 +9,9 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 16777216
 R = presets.scene_bucket_resolution(n)
 pos0, vel0 = presets.dam_break(n, 0.8, 1)
 dt = presets.bench_dt_frame(R)
+overlap = not (len(sys.argv) > 2 and sys.argv[2] == "nooverlap")
 for slabs in (1, 2, 4, 8):
-    kw = dict(device_ids=[0] * slabs) if slabs > 1 else {}
+    kw = dict(device_ids=[0] * slabs, overlap=overlap) if slabs > 1 else {}
     sim = SphFluidSimulation(particleNumber=n, bucketResolution=R, damFillRate=0.8, **kw).Start(pos0, vel0)
     sim.step_n(dt, 5); sim.synchronize()
     sim.reset_stats()

@@ -8,9 +8,10 @@ frames = int(sys.argv[2]) if len(sys.argv) > 2 else 200
 chunk = int(sys.argv[3]) if len(sys.argv) > 3 else 20
 lists = (sys.argv[4] != "nolists") if len(sys.argv) > 4 else True
 precision = int(sys.argv[5]) if len(sys.argv) > 5 else 0
+skin = float(sys.argv[6]) if len(sys.argv) > 6 else 0.0
 R = presets.scene_bucket_resolution(n)
 pos0, vel0 = presets.dam_break(n, 0.8, 1)
-sim = SphFluidSimulation(particleNumber=n, bucketResolution=R, damFillRate=0.8, profile=True, lists=lists, precision=precision).Start(pos0, vel0)
+sim = SphFluidSimulation(particleNumber=n, bucketResolution=R, damFillRate=0.8, profile=True, lists=lists, precision=precision, list_skin=skin).Start(pos0, vel0)
 dt = presets.bench_dt_frame(R)
 for f0 in range(0, frames, chunk):
     sim.reset_stats()

@@ -105,6 +105,7 @@ struct SphContext {
     uint32_t capacity = 0;            // particles the device arrays can hold
     int z_lo = 0, z_hi = 0, halo_w = 2, has_left = 0, has_right = 0;
     SlabRank *rank = nullptr;         // exchange buffers, counts, snapshot (allocated by sph_slab_configure)
+    hipStream_t comm_stream = nullptr;   // the halo refresh of a two-pass sub-step travels here while `stream` computes
     SlabGroup *group = nullptr;       // the group that steps this slab (owned by the group context, or by this context when it
                                       // is the only local member: one process per GPU)
     bool owns_group = false;
@@ -156,6 +157,8 @@ inline int fail(SphContext *ctx, int code, const char *fmt, ...)
 int do_bucket_generation(SphContext *c);
 int do_density(SphContext *c);
 int do_velpos(SphContext *c, float dt);
+int do_velpos_begin(SphContext *c, float dt);   // boundary-plane targets (two-pass sub-step of a z-slab)
+int do_velpos_end(SphContext *c, float dt);     // all the others; Swap()
 void refresh_scalars(SphContext *c);
 int engine_get_stats(SphContext *c, SphStats *out);   // sph_get_stats of ONE device context
 int slab_context_create(const SphParams *params, uint32_t capacity, SphContext **out);

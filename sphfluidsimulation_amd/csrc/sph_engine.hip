@@ -269,32 +269,67 @@ int do_density(SphContext *c)
     return SPH_OK;
 }
 
-int do_velpos(SphContext *c, float dt)
+static void velpos_fields(SphContext *c, float dt)
 {
-    if (!c->grid_valid) return fail(c, SPH_E_BAD_STATE, "UpdateVelocityAndPosition before BucketGeneration");
     c->dev.dt = dt;
     c->dev.nl_mode = c->dev.use_lists && c->nl_recorded ? kNlUse : kNlOff;
     c->dev.nl_still = c->nl_fresh ? 1u : 0u;   // first sub-step since the grid build: the recorded positions still stand
     c->nl_fresh = false;              // positions move: a later density pass of this frame must not record
-    {
-        PassTimer t(c, 2);
-        if (c->profile && c->dev.nl_mode == kNlUse) {   // the dominant kernel on its own, for the roofline figure
-            PassEvents pe{};
-            pe.kind = 3;
-            pe.a = get_event(c);
-            pe.b = get_event(c);
-            launch_velpos(c->dev, c->stream, pe.a, pe.b);
-            c->pending.push_back(pe);
-        } else {
-            launch_velpos(c->dev, c->stream);
-        }
+}
+
+static void velpos_issue(SphContext *c, uint32_t pass_mode)
+{
+    Dev d = c->dev;
+    d.pass_mode = pass_mode;
+    PassTimer t(c, 2);
+    if (c->profile && d.nl_mode == kNlUse) {   // the dominant kernel on its own, for the roofline figure
+        PassEvents pe{};
+        pe.kind = 3;
+        pe.a = get_event(c);
+        pe.b = get_event(c);
+        launch_velpos(d, c->stream, pe.a, pe.b);
+        c->pending.push_back(pe);
+    } else {
+        launch_velpos(d, c->stream);
     }
-    HIP_TRY(c, hipGetLastError());
+}
+
+static void velpos_done(SphContext *c, float dt)
+{
     std::swap(c->dev.cur, c->dev.nxt);  // Swap(), SphFluidSimulation.cs:267-268
     c->dev.wild_v_cur ^= 1u;
     c->substeps++;
     c->substeps_since_upload++;
     c->dt_last = dt;
+}
+
+int do_velpos(SphContext *c, float dt)
+{
+    if (!c->grid_valid) return fail(c, SPH_E_BAD_STATE, "UpdateVelocityAndPosition before BucketGeneration");
+    velpos_fields(c, dt);
+    velpos_issue(c, 0u);
+    HIP_TRY(c, hipGetLastError());
+    velpos_done(c, dt);
+    return SPH_OK;
+}
+
+// The same sub-step in two passes (z-slab mode): _begin issues the targets binned in the slab's boundary planes -- what the
+// neighbours hold as ghosts -- so that the caller can send their new values while _end issues all the others.  Together
+// they launch exactly what do_velpos launches, over disjoint target sets.
+int do_velpos_begin(SphContext *c, float dt)
+{
+    if (!c->grid_valid) return fail(c, SPH_E_BAD_STATE, "UpdateVelocityAndPosition before BucketGeneration");
+    velpos_fields(c, dt);
+    velpos_issue(c, 1u);
+    HIP_TRY(c, hipGetLastError());
+    return SPH_OK;
+}
+
+int do_velpos_end(SphContext *c, float dt)
+{
+    velpos_issue(c, 2u);
+    HIP_TRY(c, hipGetLastError());
+    velpos_done(c, dt);
     return SPH_OK;
 }
 

@@ -59,6 +59,13 @@ struct Dev {
     uint8_t *ghost_nxt;    // written by the reorder
     uint32_t *slot_of_src; // inverse of the reorder permutation: pre-build index -> slot
     uint32_t n_owned;      // pre-build indices [0, n_owned) are owned, [n_owned, count) are ghosts
+    // z-slab mode, a sub-step in two passes (sph_slab_frame.hip: the halo refresh of the boundary targets travels while the
+    // interior targets are computed): 0 = every target; 1 = only targets binned in the boundary planes [zone_p[0], zone_p[1])
+    // and [zone_p[2], zone_p[3]) (what the neighbours hold as ghosts); 2 = all the others
+    uint32_t pass_mode;
+    int zone_p[4];
+    uint32_t zone_blocks[2];   // 256-slot blocks that cover the owned particles of the lower / upper boundary planes (host-known:
+                               // they are the particles this slab refreshes for its neighbours)
     int zt_lo, zt_hi;      // current-cell z range an owned target may reach without leaving the halo
     int zo_lo, zo_hi;      // grid planes whose particles are targets here (whole grid outside slab mode)
     unsigned long long *counters;  // device statistics, see Counter
@@ -99,6 +106,35 @@ __device__ __forceinline__ uint32_t *nl_entries(const Dev &d, uint32_t slot)   /
 __host__ __device__ __forceinline__ uint32_t nl_bricks_x(uint32_t R) { return (R + kNlBX - 1) / kNlBX; }
 __host__ __device__ __forceinline__ uint32_t nl_bricks_y(uint32_t R) { return (R + kNlBY - 1) / kNlBY; }
 __host__ __device__ __forceinline__ uint32_t nl_bricks_z(uint32_t R) { return (R + kNlBZ - 1) / kNlBZ; }
+
+// Slot ranges of the boundary planes (slots are in bin order, z slowest): [r[0], r[1]) and [r[2], r[3]).
+struct ZoneSlots {
+    uint32_t r[4];
+};
+__device__ __forceinline__ ZoneSlots zone_slots(const Dev &d)
+{
+    ZoneSlots z;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int p = d.zone_p[k] < 0 ? 0 : (d.zone_p[k] > (int)d.R ? (int)d.R : d.zone_p[k]);
+        z.r[k] = d.cell_start[(uint32_t)p * d.R * d.R];
+    }
+    if (z.r[2] < z.r[1]) z.r[2] = z.r[1];              // (a slab thinner than two halos: the ranges must not overlap)
+    if (z.r[3] < z.r[2]) z.r[3] = z.r[2];
+    return z;
+}
+__device__ __forceinline__ bool in_zone(const ZoneSlots &z, uint32_t s) { return (s >= z.r[0] && s < z.r[1]) || (s >= z.r[2] && s < z.r[3]); }
+// does the pass in flight take a target of slot s / a brick of planes [z0, z0 + nz)?
+__device__ __forceinline__ bool pass_takes_slot(const Dev &d, const ZoneSlots &z, uint32_t s)
+{
+    return d.pass_mode == 0u || (in_zone(z, s) == (d.pass_mode == 1u));
+}
+__device__ __forceinline__ bool pass_takes_brick(const Dev &d, int z0, int nz)
+{
+    if (d.pass_mode == 0u) return true;
+    const bool touches = (z0 < d.zone_p[1] && z0 + nz > d.zone_p[0]) || (z0 < d.zone_p[3] && z0 + nz > d.zone_p[2]);
+    return touches == (d.pass_mode == 1u);
+}
 
 // Statistics every wave adds to (candidates visited, list entries walked): one counter would take ~0.5 M atomics on a
 // single address per launch, which alone costs milliseconds; they are spread over kStatStripes cache lines by block

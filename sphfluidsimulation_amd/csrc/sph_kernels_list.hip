@@ -267,8 +267,23 @@ __global__ void __launch_bounds__(kListBlock, SPH_LIST_MINWAVES) k_velpos_list(D
 {
     __shared__ uint32_t s_queue[2];
     if (nl_blocked(d)) return;                     // the scanning kernels take everything
-    const uint32_t s_raw = xcd_contiguous_block() * kListBlock + threadIdx.x;
+    uint32_t s_base = xcd_contiguous_block() * kListBlock, s_raw = s_base + threadIdx.x;
     bool live = s_raw < d.count;
+    if (d.pass_mode == 1u) {
+        // first pass of a two-pass sub-step: a SMALL grid over the two slot ranges of the boundary planes (their sizes are
+        // host-known: zone_blocks; where they start is not: cell_start)
+        const ZoneSlots z = zone_slots(d);
+        const bool lower = blockIdx.x < d.zone_blocks[0];
+        s_base = (lower ? z.r[0] + blockIdx.x * kListBlock : z.r[2] + (blockIdx.x - d.zone_blocks[0]) * kListBlock);
+        s_raw = s_base + threadIdx.x;
+        live = s_raw < (lower ? z.r[1] : z.r[3]) && s_raw < d.count;
+        if (s_base >= (lower ? z.r[1] : z.r[3])) return;                         // block-uniform
+    } else if (d.pass_mode == 2u) {                // second pass: everybody else
+        const ZoneSlots z = zone_slots(d);
+        const uint32_t s_end = s_base + kListBlock;
+        if ((s_base >= z.r[0] && s_end <= z.r[1]) || (s_base >= z.r[2] && s_end <= z.r[3])) return;   // block-uniform
+        live = live && !in_zone(z, s_raw);
+    }
     const uint32_t s = live ? s_raw : 0u;
     ListTarget t = list_target<PREC>(d, s);
     uint32_t n = d.nl_cnt[s];
@@ -388,8 +403,10 @@ void launch_list_prepare(const Dev &d, hipStream_t s)
 void launch_velpos_lists(const Dev &d, hipStream_t s, hipEvent_t list_begin, hipEvent_t list_end)
 {
     if (list_begin) (void)hipEventRecord(list_begin, s);     // the events bracket k_velpos_list alone (bench.py roofline)
-    if (d.prec == 0u) hipLaunchKernelGGL(k_velpos_list<0>, dim3(cdiv(d.count, kListBlock)), dim3(kListBlock), 0, s, d);
-    else hipLaunchKernelGGL(k_velpos_list<1>, dim3(cdiv(d.count, kListBlock)), dim3(kListBlock), 0, s, d);
+    const uint32_t blocks = d.pass_mode == 1u ? (d.zone_blocks[0] + d.zone_blocks[1] ? d.zone_blocks[0] + d.zone_blocks[1] : 1u)
+                                              : cdiv(d.count, kListBlock);
+    if (d.prec == 0u) hipLaunchKernelGGL(k_velpos_list<0>, dim3(blocks), dim3(kListBlock), 0, s, d);
+    else hipLaunchKernelGGL(k_velpos_list<1>, dim3(blocks), dim3(kListBlock), 0, s, d);
     if (list_end) (void)hipEventRecord(list_end, s);
     if (d.nl_still) return;                        // first sub-step: nobody has changed cell, nothing was handed over
     const uint32_t g = cdiv(d.count, kBlock);

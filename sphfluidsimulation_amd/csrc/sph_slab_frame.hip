@@ -65,6 +65,7 @@ struct SlabRank {
     uint32_t n_export[2] = {0, 0};   // particles refreshed for each neighbour: own exports + its kept migrants
     uint32_t n_ghost[2] = {0, 0};    // ghosts held from each neighbour: received + own kept migrants
     hipEvent_t ev_packed = nullptr, ev_pulled = nullptr;   // peer-copy transport
+    hipEvent_t ev_zone_done = nullptr, ev_refresh_done = nullptr;   // two-pass sub-step: compute stream <-> communication stream
     ncclComm_t comm = nullptr;       // RCCL transport
     // host-staged transport
     void *stage[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -83,13 +84,16 @@ struct SlabGroup;
 struct Transport {
     virtual ~Transport() {}
     virtual const char *name() const = 0;
-    // enqueue on every local slab's stream; ordered like any other work of that stream
-    virtual int exchange(SlabGroup &g, std::vector<Xfer> &x) = 0;
+    // enqueue on every local slab's stream (comm = its communication stream: the refresh of a two-pass sub-step); ordered
+    // like any other work of that stream
+    virtual int exchange(SlabGroup &g, std::vector<Xfer> &x, bool comm = false) = 0;
     // sum over ALL slabs of SlabRank::viol_dev: begin() before the synchronisation (a transport that reduces on the device
     // does it here, in place), end() after it, from the pinned copies
     virtual int allreduce_begin(SlabGroup &) { return SPH_OK; }
     virtual int allreduce_end(SlabGroup &g, unsigned long long *total) = 0;
 };
+
+static inline hipStream_t stream_of(const SphContext *m, bool comm) { return comm ? m->comm_stream : m->stream; }
 
 struct SlabGroup {
     std::vector<SphContext *> members;   // local slabs, ascending rank
@@ -100,6 +104,8 @@ struct SlabGroup {
     float delta_prev = 0.0f;
     unsigned long long viol_seen = 0;    // global violation count at the last look
     uint64_t reruns = 0;
+    bool single_pass = false;            // SPH_FLAG_NO_OVERLAP: refresh after the whole sub-step (diagnostic)
+    bool force_two_pass = false;         // SPH_FLAG_FORCE_TWO_PASS: also with one slab (diagnostic: what the second pass costs)
     SphContext *owner = nullptr;         // error messages go here
 };
 
@@ -128,7 +134,7 @@ static int gfail(SlabGroup &g, int code, const char *fmt, ...)
 // no neighbours anywhere (one slab): nothing to move
 struct NullTransport : Transport {
     const char *name() const override { return "none"; }
-    int exchange(SlabGroup &, std::vector<Xfer> &) override { return SPH_OK; }
+    int exchange(SlabGroup &, std::vector<Xfer> &, bool) override { return SPH_OK; }
     int allreduce_end(SlabGroup &g, unsigned long long *total) override
     {
         *total = 0;
@@ -142,13 +148,13 @@ struct NullTransport : Transport {
 // was packed, nobody re-packs a buffer before the neighbour has pulled it.
 struct PeerCopyTransport : Transport {
     const char *name() const override { return "peer-copy"; }
-    int exchange(SlabGroup &g, std::vector<Xfer> &x) override
+    int exchange(SlabGroup &g, std::vector<Xfer> &x, bool comm) override
     {
         const size_t L = g.members.size();
         for (size_t i = 0; i < L; i++) {
             SphContext *m = g.members[i];
             G_HIP(g, hipSetDevice(m->device));
-            G_HIP(g, hipEventRecord(m->rank->ev_packed, m->stream));
+            G_HIP(g, hipEventRecord(m->rank->ev_packed, stream_of(m, comm)));
         }
         for (size_t i = 0; i < L; i++) {
             SphContext *m = g.members[i];
@@ -160,17 +166,17 @@ struct PeerCopyTransport : Transport {
                 if (x[j].send_bytes[1 - side] != x[i].recv_bytes[side])
                     return gfail(g, SPH_E_COMM, "peer-copy transport: slab %zu expects %zu bytes from slab %zu, which sends %zu", i,
                                  x[i].recv_bytes[side], j, x[j].send_bytes[1 - side]);
-                G_HIP(g, hipStreamWaitEvent(m->stream, g.members[j]->rank->ev_packed, 0));
+                G_HIP(g, hipStreamWaitEvent(stream_of(m, comm), g.members[j]->rank->ev_packed, 0));
                 G_HIP(g, hipMemcpyPeerAsync(x[i].recv[side], m->device, x[j].send[1 - side], g.members[j]->device,
-                                            x[i].recv_bytes[side], m->stream));
+                                            x[i].recv_bytes[side], stream_of(m, comm)));
             }
-            G_HIP(g, hipEventRecord(m->rank->ev_pulled, m->stream));
+            G_HIP(g, hipEventRecord(m->rank->ev_pulled, stream_of(m, comm)));
         }
         for (size_t i = 0; i < L; i++) {
             SphContext *m = g.members[i];
             G_HIP(g, hipSetDevice(m->device));
-            if (i > 0) G_HIP(g, hipStreamWaitEvent(m->stream, g.members[i - 1]->rank->ev_pulled, 0));
-            if (i + 1 < L) G_HIP(g, hipStreamWaitEvent(m->stream, g.members[i + 1]->rank->ev_pulled, 0));
+            if (i > 0) G_HIP(g, hipStreamWaitEvent(stream_of(m, comm), g.members[i - 1]->rank->ev_pulled, 0));
+            if (i + 1 < L) G_HIP(g, hipStreamWaitEvent(stream_of(m, comm), g.members[i + 1]->rank->ev_pulled, 0));
         }
         return SPH_OK;
     }
@@ -253,7 +259,7 @@ struct RcclTransport : Transport {
     RcclApi *api;
     explicit RcclTransport(RcclApi *a) : api(a) {}
     const char *name() const override { return "rccl"; }
-    int exchange(SlabGroup &g, std::vector<Xfer> &x) override
+    int exchange(SlabGroup &g, std::vector<Xfer> &x, bool comm) override
     {
         bool any = false;
         for (const Xfer &t : x) any = any || t.send_bytes[0] || t.send_bytes[1] || t.recv_bytes[0] || t.recv_bytes[1];
@@ -266,9 +272,9 @@ struct RcclTransport : Transport {
             for (int side = 0; side < 2; side++) {
                 const int peer = side == 0 ? r->rank - 1 : r->rank + 1;
                 if (x[i].send_bytes[side])
-                    G_NCCL(g, api, api->Send(x[i].send[side], x[i].send_bytes[side], ncclChar, peer, r->comm, m->stream));
+                    G_NCCL(g, api, api->Send(x[i].send[side], x[i].send_bytes[side], ncclChar, peer, r->comm, stream_of(m, comm)));
                 if (x[i].recv_bytes[side])
-                    G_NCCL(g, api, api->Recv(x[i].recv[side], x[i].recv_bytes[side], ncclChar, peer, r->comm, m->stream));
+                    G_NCCL(g, api, api->Recv(x[i].recv[side], x[i].recv_bytes[side], ncclChar, peer, r->comm, stream_of(m, comm)));
             }
         }
         G_NCCL(g, api, api->GroupEnd());
@@ -301,7 +307,7 @@ struct HostTransport : Transport {
     void *user;
     HostTransport(SphHostExchangeFn e, SphHostAllreduceFn a, void *u) : exchange_fn(e), allreduce_fn(a), user(u) {}
     const char *name() const override { return "host-staged"; }
-    int exchange(SlabGroup &g, std::vector<Xfer> &x) override
+    int exchange(SlabGroup &g, std::vector<Xfer> &x, bool comm) override
     {
         if (g.members.size() != 1) return gfail(g, SPH_E_COMM, "host transport: one slab per process");
         SphContext *m = g.members[0];
@@ -318,14 +324,14 @@ struct HostTransport : Transport {
                 r->stage_bytes[k] = bytes;
             }
         for (int side = 0; side < 2; side++)
-            if (need[side]) G_HIP(g, hipMemcpyAsync(r->stage[side], x[0].send[side], need[side], hipMemcpyDeviceToHost, m->stream));
-        G_HIP(g, hipStreamSynchronize(m->stream));
+            if (need[side]) G_HIP(g, hipMemcpyAsync(r->stage[side], x[0].send[side], need[side], hipMemcpyDeviceToHost, stream_of(m, comm)));
+        G_HIP(g, hipStreamSynchronize(stream_of(m, comm)));
         m->host_syncs++;
         const int rc = exchange_fn(user, r->stage[0], need[0], r->stage[1], need[1], r->stage[2], need[2], r->stage[3], need[3]);
         if (rc != 0) return gfail(g, SPH_E_COMM, "host transport: the exchange callback returned %d", rc);
         for (int side = 0; side < 2; side++)
             if (need[2 + side])
-                G_HIP(g, hipMemcpyAsync(x[0].recv[side], r->stage[2 + side], need[2 + side], hipMemcpyHostToDevice, m->stream));
+                G_HIP(g, hipMemcpyAsync(x[0].recv[side], r->stage[2 + side], need[2 + side], hipMemcpyHostToDevice, stream_of(m, comm)));
         return SPH_OK;
     }
     int allreduce_end(SlabGroup &g, unsigned long long *total) override
@@ -366,6 +372,11 @@ static void apply_halo(SphContext *c, int halo_w)
     c->dev.zt_hi = c->has_right ? c->z_hi - 1 + (halo_w - 1) : INT_MAX;
     c->dev.zo_lo = c->z_lo;   // bricks made only of ghost planes have no targets and return at once
     c->dev.zo_hi = c->z_hi;
+    // the boundary planes of a two-pass sub-step: exactly the planes whose owned particles the neighbours hold as ghosts
+    c->dev.zone_p[0] = c->has_left ? c->z_lo : 0;
+    c->dev.zone_p[1] = c->has_left ? std::min(c->z_lo + halo_w, c->z_hi) : 0;
+    c->dev.zone_p[2] = c->has_right ? std::max(c->z_hi - halo_w, c->z_lo) : 0;
+    c->dev.zone_p[3] = c->has_right ? c->z_hi : 0;
 }
 
 template <typename T>
@@ -390,6 +401,10 @@ void slab_rank_destroy(SphContext *c)
         if (p) (void)hipHostFree(p);
     if (r->ev_packed) (void)hipEventDestroy(r->ev_packed);
     if (r->ev_pulled) (void)hipEventDestroy(r->ev_pulled);
+    if (r->ev_zone_done) (void)hipEventDestroy(r->ev_zone_done);
+    if (r->ev_refresh_done) (void)hipEventDestroy(r->ev_refresh_done);
+    if (c->comm_stream) (void)hipStreamDestroy(c->comm_stream);
+    c->comm_stream = nullptr;
     delete r;
     c->rank = nullptr;
 }
@@ -448,6 +463,9 @@ int slab_configure(SphContext *c, int rank, int world)
     memset(r->host, 0, sizeof(SlabHost));
     HIP_TRY(c, hipEventCreateWithFlags(&r->ev_packed, hipEventDisableTiming));
     HIP_TRY(c, hipEventCreateWithFlags(&r->ev_pulled, hipEventDisableTiming));
+    HIP_TRY(c, hipEventCreateWithFlags(&r->ev_zone_done, hipEventDisableTiming));
+    HIP_TRY(c, hipEventCreateWithFlags(&r->ev_refresh_done, hipEventDisableTiming));
+    HIP_TRY(c, hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
     return SPH_OK;
 }
 
@@ -459,6 +477,8 @@ SlabGroup *slab_group_new(SphContext *owner, std::vector<SphContext *> members, 
     g->owner = owner;
     g->halo_w = g->members[0]->halo_w;
     g->max_halo = group_max_halo((int)g->members[0]->dev.R, world);
+    g->single_pass = (g->members[0]->params.flags & SPH_FLAG_NO_OVERLAP) != 0;
+    g->force_two_pass = (g->members[0]->params.flags & SPH_FLAG_FORCE_TWO_PASS) != 0;
     if (world == 1) g->transport.reset(new NullTransport());
     for (SphContext *m : g->members) m->group = g;
     return g;
@@ -721,6 +741,9 @@ static int phase_payload(SlabGroup &g)
             at += r->kept_n[s];
         }
         m->dev.count = at;
+        // the owned particles of the boundary planes are the ones refreshed for the neighbours: their number bounds the grid
+        // of a two-pass sub-step's first pass (+1 block: the ranges start at any slot)
+        for (int s = 0; s < 2; s++) m->dev.zone_blocks[s] = r->n_export[s] ? (r->n_export[s] + 255u) / 256u + 1u : 0u;
         G_HIP(g, hipGetLastError());
         // (the owned particles as the frame finds them -- what a re-run with a wider halo starts from -- are parked by
         // phase_compute once the grid build has read them: no copy)
@@ -733,17 +756,29 @@ static int phase_payload(SlabGroup &g)
     return SPH_OK;
 }
 
-// ghost values follow their owners: what = SPH_SLAB_UPDATE_RHO after the density pass, POSVEL after a sub-step
-static int refresh_ghosts(SlabGroup &g, int what)
+// ghost values follow their owners: what = SPH_SLAB_UPDATE_RHO after the density pass, POSVEL after a sub-step.
+// overlapped: the sub-step is being issued in two passes (do_velpos_begin done, do_velpos_end not yet): the refresh runs
+// on the communication streams behind the first pass and reads / writes the arrays the sub-step is WRITING (nxt) -- the
+// boundary targets' new values out, the ghosts' new values in; the second pass touches neither.
+static int refresh_ghosts(SlabGroup &g, int what, bool overlapped)
 {
     const size_t words = what == 0 ? 1 : kSlabPosVelWords;
     std::vector<Xfer> x(g.members.size());
+    std::vector<Dev> view(g.members.size());
     for (size_t i = 0; i < g.members.size(); i++) {
         SphContext *m = g.members[i];
         SlabRank *r = m->rank;
         G_HIP(g, hipSetDevice(m->device));
+        view[i] = m->dev;
+        if (overlapped) {
+            std::swap(view[i].cur, view[i].nxt);         // what Swap() will make current
+            view[i].wild_v_cur ^= 1u;
+            G_HIP(g, hipEventRecord(r->ev_zone_done, m->stream));
+            G_HIP(g, hipStreamWaitEvent(m->comm_stream, r->ev_zone_done, 0));
+        }
+        const hipStream_t st = stream_of(m, overlapped);
         for (int s = 0; s < 2; s++) {
-            launch_slab_pack_update(m->dev, r->send_src[s], r->n_export[s], what, r->send_ghost[s], m->stream);
+            launch_slab_pack_update(view[i], r->send_src[s], r->n_export[s], what, r->send_ghost[s], st);
             x[i].send[s] = r->send_ghost[s];
             x[i].recv[s] = r->recv_ghost[s];
             x[i].send_bytes[s] = (size_t)r->n_export[s] * words * sizeof(float);
@@ -751,15 +786,17 @@ static int refresh_ghosts(SlabGroup &g, int what)
         }
         G_HIP(g, hipGetLastError());
     }
-    int rc = g.transport->exchange(g, x);
+    int rc = g.transport->exchange(g, x, overlapped);
     if (rc != SPH_OK) return rc;
-    EACH(g, m)
-    {
+    for (size_t i = 0; i < g.members.size(); i++) {
+        SphContext *m = g.members[i];
         SlabRank *r = m->rank;
         G_HIP(g, hipSetDevice(m->device));
-        launch_slab_unpack_update(m->dev, m->dev.n_owned, r->n_ghost[0], what, r->recv_ghost[0], m->stream);
-        launch_slab_unpack_update(m->dev, m->dev.n_owned + r->n_ghost[0], r->n_ghost[1], what, r->recv_ghost[1], m->stream);
+        const hipStream_t st = stream_of(m, overlapped);
+        launch_slab_unpack_update(view[i], m->dev.n_owned, r->n_ghost[0], what, r->recv_ghost[0], st);
+        launch_slab_unpack_update(view[i], m->dev.n_owned + r->n_ghost[0], r->n_ghost[1], what, r->recv_ghost[1], st);
         G_HIP(g, hipGetLastError());
+        if (overlapped) G_HIP(g, hipEventRecord(r->ev_refresh_done, m->comm_stream));
     }
     return SPH_OK;
 }
@@ -785,15 +822,34 @@ static int phase_compute(SlabGroup &g, float delta_time)
         std::swap(m->dev.id_nxt, r->snap_id);
         if ((rc = do_density(m)) != SPH_OK) return rc;             // :99
     }
-    if ((rc = refresh_ghosts(g, SPH_SLAB_UPDATE_RHO)) != SPH_OK) return rc;
+    if ((rc = refresh_ghosts(g, SPH_SLAB_UPDATE_RHO, false)) != SPH_OK) return rc;
     const uint32_t S = g.members[0]->params.substeps;
+    // A sub-step whose results the neighbours need goes in TWO passes: the targets binned in the boundary planes first, then
+    // -- while their new positions and velocities travel on the communication stream -- everybody else.
+    const bool two_pass = (g.world > 1 || g.force_two_pass) && g.members[0]->dev.use_bricks != 0u && !g.single_pass;
     for (uint32_t i = 0; i < S; i++) {                             // :101
+        const bool refresh = i + 1 < S;
+        if (!(refresh && two_pass)) {
+            EACH(g, m)
+            {
+                G_HIP(g, hipSetDevice(m->device));
+                if ((rc = do_velpos(m, delta_time / m->params.dt_divisor)) != SPH_OK) return rc;   // :102
+            }
+            if (refresh && (rc = refresh_ghosts(g, SPH_SLAB_UPDATE_POSVEL, false)) != SPH_OK) return rc;
+            continue;
+        }
         EACH(g, m)
         {
             G_HIP(g, hipSetDevice(m->device));
-            if ((rc = do_velpos(m, delta_time / m->params.dt_divisor)) != SPH_OK) return rc;   // :102
+            if ((rc = do_velpos_begin(m, delta_time / m->params.dt_divisor)) != SPH_OK) return rc;
         }
-        if (i + 1 < S && (rc = refresh_ghosts(g, SPH_SLAB_UPDATE_POSVEL)) != SPH_OK) return rc;
+        if ((rc = refresh_ghosts(g, SPH_SLAB_UPDATE_POSVEL, true)) != SPH_OK) return rc;
+        EACH(g, m)
+        {
+            G_HIP(g, hipSetDevice(m->device));
+            if ((rc = do_velpos_end(m, delta_time / m->params.dt_divisor)) != SPH_OK) return rc;
+            G_HIP(g, hipStreamWaitEvent(m->stream, m->rank->ev_refresh_done, 0));   // the next sub-step reads the ghosts
+        }
     }
     return SPH_OK;
 }
