@@ -101,8 +101,6 @@ static int validate(SphContext *ctx, const SphParams *p)
     if (p->substeps == 0 || p->substeps > 1000) return fail(ctx, SPH_E_INVALID_ARG, "substeps out of range");
     if (!(p->dt_divisor > 0.0f)) return fail(ctx, SPH_E_INVALID_ARG, "dt_divisor must be > 0");
     if (p->precision > 1) return fail(ctx, SPH_E_UNSUPPORTED, "precision %u not supported (0 = fp32, 1 = fp16 positions)", p->precision);
-    if (p->precision == 1 && p->num_devices > 1)
-        return fail(ctx, SPH_E_UNSUPPORTED, "precision 1 (fp16 positions) is single-device in this version");
     if (p->exact_order != 1) return fail(ctx, SPH_E_UNSUPPORTED, "exact_order=0 (fast mode) is not built in this version");
     if (p->num_devices > 8) return fail(ctx, SPH_E_INVALID_ARG, "num_devices %u > 8", p->num_devices);
     if (p->halo_planes > 128) return fail(ctx, SPH_E_INVALID_ARG, "halo_planes %u > 128", p->halo_planes);
@@ -448,10 +446,6 @@ static int create_common(const SphParams *params, uint32_t capacity, bool slab, 
     A(dalloc(c, &d.id, n));
     A(dalloc(c, &d.id_nxt, n));
     if (d.prec) {
-        if (slab) {
-            fail(c, SPH_E_UNSUPPORTED, "precision 1 (fp16 positions) is not available for z-slab contexts in this version");
-            return bail(SPH_E_UNSUPPORTED);
-        }
         A(dalloc(c, &d.cellkey, n));
         A(dalloc(c, &d.cellkey_nxt, n));
     }

@@ -20,11 +20,39 @@ constexpr int kBlock = 256;
 constexpr uint32_t kNoTag = 0xFFFFFFFFu;
 constexpr int kClassifyBlock = 1024;   // one atomic on the keeper counter per workgroup: ~3 ns each on that single address
 
+// The three position words of a record: x y z (fp32), or -- SphParams.precision = 1 -- the slot's fp16 record and its reference
+// cell, bit for bit: a ghost must hold EXACTLY what its owner holds, and decode / encode is not the identity.
+struct PosWords {
+    float w0, w1, w2;
+};
+__device__ __forceinline__ PosWords get_pos_words(const Dev &d, const Soa &a, const uint32_t *cellkey, uint32_t p)
+{
+    if (d.prec == 0u) return PosWords{a.x[p], a.y[p], a.z[p]};
+    const uint2 o = a.h4[p];
+    return PosWords{__uint_as_float(o.x), __uint_as_float(o.y), __uint_as_float(cellkey[p])};
+}
+// cellkey == nullptr: the slot keeps its reference cell (a refresh inside the frame)
+__device__ __forceinline__ void put_pos_words(const Dev &d, const Soa &a, uint32_t *cellkey, uint32_t p, PosWords w)
+{
+    if (d.prec == 0u) {
+        a.x[p] = w.w0; a.y[p] = w.w1; a.z[p] = w.w2;
+    } else {
+        a.h4[p] = make_uint2(__float_as_uint(w.w0), __float_as_uint(w.w1));
+        if (cellkey) cellkey[p] = __float_as_uint(w.w2);
+    }
+}
+__device__ __forceinline__ Pos3 words_to_pos(const Dev &d, PosWords w)
+{
+    if (d.prec == 0u) return Pos3{w.w0, w.w1, w.w2};
+    return decode_pos(d, make_uint2(__float_as_uint(w.w0), __float_as_uint(w.w1)), __float_as_uint(w.w2));
+}
+
 __device__ __forceinline__ void write_record(float *buf, uint32_t k, const Dev &d, uint32_t p, uint32_t tag)
 {
     float *r = buf + (size_t)kSlabRecordWords * k;
     const float4 rv = d.cur.rv[p];
-    r[0] = d.cur.x[p]; r[1] = d.cur.y[p]; r[2] = d.cur.z[p];
+    const PosWords w = get_pos_words(d, d.cur, d.cellkey, p);
+    r[0] = w.w0; r[1] = w.w1; r[2] = w.w2;
     r[3] = rv.x; r[4] = rv.y; r[5] = rv.z; r[6] = rv.w;
     r[7] = d.cur.vw[p];
     r[8] = __uint_as_float(d.id[p]);
@@ -68,15 +96,17 @@ __global__ void __launch_bounds__(kClassifyBlock) k_slab_classify(Dev d, SlabArg
     int cz = 0;
     bool in_grid = false;
     // every load of the particle is issued before the first barrier of the compaction (one latency, not two)
-    float px = 0.0f, py = 0.0f, pz = 0.0f, pvw = 0.0f;
+    PosWords pw{0.0f, 0.0f, 0.0f};
+    float pvw = 0.0f;
     float4 prv = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     uint32_t pid = 0;
     if (s < d.count && !d.ghost[s]) {
-        px = d.cur.x[s]; py = d.cur.y[s]; pz = d.cur.z[s];
+        pw = get_pos_words(d, d.cur, d.cellkey, s);
         prv = d.cur.rv[s];
         pvw = d.cur.vw[s];
         pid = d.id[s];
-        const uint32_t key = bucket_key(d, px, py, pz);
+        const Pos3 q = words_to_pos(d, pw);
+        const uint32_t key = bucket_key(d, q.x, q.y, q.z);
         dest = 0;
         in_grid = key < d.num_cells;
         if (in_grid) {
@@ -90,7 +120,7 @@ __global__ void __launch_bounds__(kClassifyBlock) k_slab_classify(Dev d, SlabArg
     if (lost) atomicAdd(&a.counters[kSlabLost], 1u);
     const uint32_t k = block_append(dest == 0, &a.counters[kSlabKeep], s_cnt);
     if (dest == 0) {
-        d.nxt.x[k] = px; d.nxt.y[k] = py; d.nxt.z[k] = pz;
+        put_pos_words(d, d.nxt, d.cellkey_nxt, k, pw);
         d.nxt.rv[k] = prv;
         d.nxt.vw[k] = pvw;
         d.id_nxt[k] = pid;
@@ -139,7 +169,8 @@ __global__ void __launch_bounds__(kBlock) k_slab_append(Dev d, const float *__re
     if (k >= n) return;
     const float *r = recv + (size_t)kSlabRecordWords * k;
     const uint32_t p = at + k;
-    d.cur.x[p] = r[0]; d.cur.y[p] = r[1]; d.cur.z[p] = r[2];
+    const PosWords w{r[0], r[1], r[2]};
+    put_pos_words(d, d.cur, d.cellkey, p, w);
     d.cur.rv[p] = make_float4(r[3], r[4], r[5], r[6]);
     d.cur.vw[p] = r[7];
     d.id[p] = __float_as_uint(r[8]);
@@ -153,7 +184,8 @@ __global__ void __launch_bounds__(kBlock) k_slab_append(Dev d, const float *__re
         }
         // a migrant must land in this slab, and not in the boundary planes of the FAR face (it would have to be
         // forwarded as a ghost: slabs are at least 2 W planes thick, so only a particle that outran the halo gets there)
-        const uint32_t key = bucket_key(d, r[0], r[1], r[2]);
+        const Pos3 q = words_to_pos(d, w);
+        const uint32_t key = bucket_key(d, q.x, q.y, q.z);
         bool bad = key >= d.num_cells;
         if (!bad) {
             const int cz = (int)(key / (d.R * d.R));
@@ -177,7 +209,8 @@ __global__ void __launch_bounds__(kBlock) k_slab_pack_update(Dev d, const uint32
         out[k] = rv.x;
     } else {
         float *r = out + 7ull * k;
-        r[0] = d.cur.x[s]; r[1] = d.cur.y[s]; r[2] = d.cur.z[s];
+        const PosWords w = get_pos_words(d, d.cur, d.cellkey, s);
+        r[0] = w.w0; r[1] = w.w1; r[2] = w.w2;
         r[3] = rv.x; r[4] = rv.y; r[5] = rv.z; r[6] = rv.w;
     }
 }
@@ -193,22 +226,25 @@ __global__ void __launch_bounds__(kBlock) k_slab_unpack_update(Dev d, uint32_t s
         if (is_wild_density(d, in[k])) d.counters[kCntWildP] = 1ull;    // (as the density pass does for local particles)
     } else {
         const float *r = in + 7ull * k;
-        d.cur.x[s] = r[0]; d.cur.y[s] = r[1]; d.cur.z[s] = r[2];
-        if (d.cur.p4) d.cur.p4[s] = make_float4(r[0], r[1], r[2], 0.0f);   // the packed copy the list kernel gathers
+        put_pos_words(d, d.cur, nullptr, s, PosWords{r[0], r[1], r[2]});      // (the ghost slot keeps its reference cell: same as its owner's)
+        if (d.cur.p4) {                                                       // the packed copy the list kernel gathers
+            if (d.prec == 0u) d.cur.p4[s] = make_float4(r[0], r[1], r[2], 0.0f);
+            else reinterpret_cast<uint4 *>(d.cur.p4)[s] = make_uint4(__float_as_uint(r[0]), __float_as_uint(r[1]), d.cellkey[s], 0u);
+        }
         d.cur.rv[s] = make_float4(r[3], r[4], r[5], r[6]);
         if (is_wild(r[4]) || is_wild(r[5]) || is_wild(r[6])) d.counters[kCntWildV0 + d.wild_v_cur] = 1ull;
     }
 }
 
 // Back to the owned particles a frame started from (re-run with a wider halo): no ghosts, unsorted, wild flag re-raised.
-__global__ void __launch_bounds__(kBlock) k_slab_restore(Dev d, uint32_t n, const float *__restrict__ x, const float *__restrict__ y,
-                                                         const float *__restrict__ z, const float4 *__restrict__ rv,
-                                                         const float *__restrict__ vw, const uint32_t *__restrict__ id)
+__global__ void __launch_bounds__(kBlock) k_slab_restore(Dev d, uint32_t n, Soa snap, const uint32_t *__restrict__ snap_ck,
+                                                         const float4 *__restrict__ rv, const float *__restrict__ vw,
+                                                         const uint32_t *__restrict__ id)
 {
     const uint32_t p = blockIdx.x * kBlock + threadIdx.x;
     if (p >= n) return;
     const float4 v = rv[p];
-    d.cur.x[p] = x[p]; d.cur.y[p] = y[p]; d.cur.z[p] = z[p];
+    put_pos_words(d, d.cur, d.cellkey, p, get_pos_words(d, snap, snap_ck, p));
     d.cur.rv[p] = v;
     d.cur.vw[p] = vw[p];
     d.id[p] = id[p];
@@ -228,7 +264,9 @@ __global__ void __launch_bounds__(kBlock) k_slab_download(Dev d, int substeps_do
     const float vw = d.cur.vw[s];
     const float pw = substeps_done > 0 ? clamp01(1.0f + dt_last * vw) : 1.0f;   // VelPos.compute:153-154
     ids[k] = d.id[s];
-    pos4[k] = make_float4(d.cur.x[s], d.cur.y[s], d.cur.z[s], pw);
+    Pos3 q = load_pos(d, d.cur, s);
+    if (d.prec && substeps_done > 0) q = Pos3{clamp01(q.x), clamp01(q.y), clamp01(q.z)};   // (VelPos.compute:154 clamped before the rounding)
+    pos4[k] = make_float4(q.x, q.y, q.z, pw);
     vel4[k] = make_float4(rv.y, rv.z, rv.w, vw);
     rho[k] = rv.x;
 }
@@ -241,7 +279,11 @@ __global__ void __launch_bounds__(kBlock) k_slab_upload(Dev d, uint32_t n, const
     const float4 q = pos4[p];
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (vel4) v = vel4[p];
-    d.cur.x[p] = q.x; d.cur.y[p] = q.y; d.cur.z[p] = q.z;
+    if (d.prec) {                                      // reference cell of an uploaded particle: the cell it is in
+        const int R = (int)d.R;
+        d.cellkey[p] = pack_cellkey(cell_coord(q.x, d.Rm1, R), cell_coord(q.y, d.Rm1, R), cell_coord(q.z, d.Rm1, R));
+    }
+    store_pos(d, d.cur, p, Pos3{q.x, q.y, q.z});
     d.cur.rv[p] = make_float4(0.0f, v.x, v.y, v.z);
     d.cur.vw[p] = v.w;
     d.id[p] = ids[p];
@@ -267,10 +309,10 @@ void launch_slab_append(const Dev &d, const float *recv, uint32_t n, uint32_t at
     if (n) hipLaunchKernelGGL(k_slab_append, grid_for(n), dim3(kBlock), 0, s, d, recv, n, at, send_src, own, cap_src, a, from_side);
 }
 
-void launch_slab_restore(const Dev &d, uint32_t n, const float *x, const float *y, const float *z, const float4 *rv, const float *vw,
+void launch_slab_restore(const Dev &d, uint32_t n, const Soa &snap, const uint32_t *snap_ck, const float4 *rv, const float *vw,
                          const uint32_t *id, hipStream_t s)
 {
-    if (n) hipLaunchKernelGGL(k_slab_restore, grid_for(n), dim3(kBlock), 0, s, d, n, x, y, z, rv, vw, id);
+    if (n) hipLaunchKernelGGL(k_slab_restore, grid_for(n), dim3(kBlock), 0, s, d, n, snap, snap_ck, rv, vw, id);
 }
 
 void launch_slab_pack_update(const Dev &d, const uint32_t *send_src, uint32_t n, int what, float *out, hipStream_t s)

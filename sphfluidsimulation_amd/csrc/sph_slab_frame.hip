@@ -54,6 +54,8 @@ struct SlabRank {
     SlabHost *host = nullptr;
     // owned particles at the start of the frame in flight (after migration): what a re-run starts from
     float *snap_x = nullptr, *snap_y = nullptr, *snap_z = nullptr, *snap_vw = nullptr;
+    uint2 *snap_h4 = nullptr;     // precision 1: the fp16 records and their reference cells instead of x, y, z
+    uint32_t *snap_ck = nullptr;
     float4 *snap_rv = nullptr;
     uint32_t *snap_id = nullptr;
     uint32_t snap_n = 0;
@@ -452,8 +454,13 @@ int slab_configure(SphContext *c, int rank, int world)
     if ((rc = ralloc(c, &r->counters, (size_t)kSlabCounterCount)) != SPH_OK || (rc = ralloc(c, &r->hdr_send, (size_t)8)) != SPH_OK ||
         (rc = ralloc(c, &r->hdr_recv, (size_t)8)) != SPH_OK || (rc = ralloc(c, &r->viol_dev, (size_t)1)) != SPH_OK)
         return rc;
-    if ((rc = ralloc(c, &r->snap_x, n)) != SPH_OK || (rc = ralloc(c, &r->snap_y, n)) != SPH_OK || (rc = ralloc(c, &r->snap_z, n)) != SPH_OK ||
-        (rc = ralloc(c, &r->snap_vw, n)) != SPH_OK || (rc = ralloc(c, &r->snap_rv, n)) != SPH_OK || (rc = ralloc(c, &r->snap_id, n)) != SPH_OK)
+    if (c->dev.prec == 0u) {
+        if ((rc = ralloc(c, &r->snap_x, n)) != SPH_OK || (rc = ralloc(c, &r->snap_y, n)) != SPH_OK || (rc = ralloc(c, &r->snap_z, n)) != SPH_OK)
+            return rc;
+    } else if ((rc = ralloc(c, &r->snap_h4, n)) != SPH_OK || (rc = ralloc(c, &r->snap_ck, n)) != SPH_OK) {
+        return rc;
+    }
+    if ((rc = ralloc(c, &r->snap_vw, n)) != SPH_OK || (rc = ralloc(c, &r->snap_rv, n)) != SPH_OK || (rc = ralloc(c, &r->snap_id, n)) != SPH_OK)
         return rc;
     HIP_TRY(c, hipMemset(r->counters, 0, kSlabCounterCount * sizeof(uint32_t)));   // (kSlabMisplaced accumulates from here on)
     HIP_TRY(c, hipMemset(r->hdr_send, 0, 8 * sizeof(uint32_t)));
@@ -718,6 +725,7 @@ static int phase_payload(SlabGroup &g)
     {
         std::swap(m->dev.cur, m->dev.nxt);              // the keepers were compacted into nxt
         std::swap(m->dev.id, m->dev.id_nxt);
+        std::swap(m->dev.cellkey, m->dev.cellkey_nxt);
         m->dev.count = m->dev.n_owned = m->rank->n_keep;
         m->grid_valid = false;
     }
@@ -817,6 +825,8 @@ static int phase_compute(SlabGroup &g, float delta_time)
         std::swap(m->dev.nxt.x, r->snap_x);
         std::swap(m->dev.nxt.y, r->snap_y);
         std::swap(m->dev.nxt.z, r->snap_z);
+        std::swap(m->dev.nxt.h4, r->snap_h4);
+        std::swap(m->dev.cellkey_nxt, r->snap_ck);
         std::swap(m->dev.nxt.vw, r->snap_vw);
         std::swap(m->dev.nxt.rv, r->snap_rv);
         std::swap(m->dev.id_nxt, r->snap_id);
@@ -854,7 +864,7 @@ static int phase_compute(SlabGroup &g, float delta_time)
     return SPH_OK;
 }
 
-void launch_slab_restore(const Dev &d, uint32_t n, const float *x, const float *y, const float *z, const float4 *rv, const float *vw,
+void launch_slab_restore(const Dev &d, uint32_t n, const Soa &snap, const uint32_t *snap_ck, const float4 *rv, const float *vw,
                          const uint32_t *id, hipStream_t s);   // sph_kernels_slab.hip
 
 // The frame issued last broke its halo somewhere: every slab goes back to its snapshot and runs it again with a wider one.
@@ -874,7 +884,12 @@ static int rerun_previous(SlabGroup &g)
         m->dev.count = m->dev.n_owned = r->snap_n;
         G_HIP(g, hipMemsetAsync(m->dev.ghost, 0, m->capacity, m->stream));
         G_HIP(g, hipMemsetAsync(m->dev.counters + kCntWildV0 + m->dev.wild_v_cur, 0, sizeof(unsigned long long), m->stream));
-        launch_slab_restore(m->dev, r->snap_n, r->snap_x, r->snap_y, r->snap_z, r->snap_rv, r->snap_vw, r->snap_id, m->stream);
+        Soa snap{};
+        snap.x = r->snap_x;
+        snap.y = r->snap_y;
+        snap.z = r->snap_z;
+        snap.h4 = r->snap_h4;
+        launch_slab_restore(m->dev, r->snap_n, snap, r->snap_ck, r->snap_rv, r->snap_vw, r->snap_id, m->stream);
         G_HIP(g, hipGetLastError());
         m->grid_valid = false;
         m->frames--;                                    // (the re-run counts it again)

@@ -162,7 +162,7 @@ class SlabSimulation:
                  viscosity: float = 0.01, restDensity: float = 1.5, gasConstant: float = 150.0,
                  stiffnessCoefficient: float = 5000.0, dampingCoefficient: float = 10.0, device_id: int = 0,
                  halo_w: int = 2, capacity_factor: float = 1.6, profile: bool = False, group=None,
-                 transport: str = "auto"):
+                 transport: str = "auto", precision: int = 0):
         self.rank, self.world = rank, world
         self.halo_w = halo_w
         self.capacity_factor = capacity_factor
@@ -179,6 +179,7 @@ class SlabSimulation:
         p.stiffness_coeff, p.damping_coeff = stiffnessCoefficient, dampingCoefficient
         p.device_id = device_id
         p.halo_planes = int(halo_w)
+        p.precision = int(precision)                  # 1: fp16 position records (BASELINE config 5), see include/sph_hip.h
         p.flags = (N.SPH_FLAG_PROFILE if profile else 0) | int(__import__('os').environ.get('SPH_SLAB_FLAGS', '0'))   # (diagnostic flags, e.g. 64 / 128)
         self._params = p
         self.R = int(bucketResolution)

@@ -19,11 +19,11 @@ from tests.test_gpu_parity import SCENE, assert_parity
 pytestmark = pytest.mark.gpu
 
 
-def run_slabs(world, n, R, frames, speed, halo_w=2, seed=21):
+def run_slabs(world, n, R, frames, speed, halo_w=2, seed=21, precision=0):
     import torch.multiprocessing as mp
     from tests import dist_workers
     with tempfile.TemporaryDirectory() as d:
-        mp.spawn(dist_workers.slab_worker, args=(world, free_port(), d, n, R, frames, speed, halo_w, seed),
+        mp.spawn(dist_workers.slab_worker, args=(world, free_port(), d, n, R, frames, speed, halo_w, seed, precision),
                  nprocs=world, join=True)
         return dict(np.load(os.path.join(d, "slab.npz")))
 
@@ -120,6 +120,35 @@ def test_halo_violation_is_repaired(oracle):
     for f in range(frames + 1):
         assert_parity(got[f"pos_f{f}"], want[f][0], f"repaired 2 ranks frame {f}: pos")
         assert_parity(got[f"vel_f{f}"], want[f][1], f"repaired 2 ranks frame {f}: vel")
+
+
+@pytest.mark.parametrize("slabs,n,R,speed,frames", [(2, 32768, 24, 0.0, 4), (3, 32768, 24, 5.0, 3), (4, 262144, 47, 1.0, 3)])
+def test_fp16_positions_in_slabs_match_one_device(slabs, n, R, speed, frames):
+    """SphParams.precision = 1 with several slabs (BASELINE config 5 is quoted on 8 GPUs): records and reference cells cross
+    the slab boundary bit for bit, so the result is IDENTICAL to the one-device precision-1 engine -- the halo repair
+    (speed 5.0 outruns two planes) included.  The one-device engine is what tests/test_gpu_precision.py ties to the oracle."""
+    from sphfluidsimulation_amd.simulation import SphFluidSimulation
+    pos0, vel0 = initial_state(n, speed)
+    dt = presets.bench_dt_frame(R)
+    one = SphFluidSimulation(particleNumber=n, bucketResolution=R, damFillRate=0.8, precision=1).Start(pos0, vel0)
+    many = group_engine(n, R, slabs, precision=1).Start(pos0, vel0)
+    try:
+        for f in range(frames + 1):
+            if f:
+                one.Update(dt)
+                many.Update(dt)
+            a, b = one.download(), many.download()
+            for x, y, what in zip(a, b, ("pos", "vel", "rho")):
+                assert_parity(y, x, f"precision 1, {slabs} slabs, frame {f}: {what}")
+        st = many.stats()
+        assert (st["frames_rerun"] >= 1) == (speed >= 5.0), st["frames_rerun"]
+        if slabs == 2:                                   # the same through one process per slab (host transport)
+            got = run_slabs(2, n, R, frames, speed, precision=1)
+            for k, what in enumerate(("pos", "vel", "rho")):
+                assert_parity(got[f"{what}_f{frames}"], a[k], f"precision 1, 2 ranks, frame {frames}: {what}")
+    finally:
+        one.OnDestroy()
+        many.OnDestroy()
 
 
 def test_halo_cannot_grow_is_an_error():
