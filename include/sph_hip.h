@@ -68,7 +68,10 @@ typedef struct SphParams {
     uint32_t precision;         /* 0 = fp32 state (bit-identical to the CPU oracle); 1 = positions stored as fp16 offsets
                                    from the centre of the particle's grid cell (8 B instead of 12), all arithmetic and the
                                    velocities fp32 -- BASELINE config 5; within 1e-4 of the fp32 result after a frame         */
-    uint32_t exact_order;       /* 1 = accumulate neighbours in the reference's x,y,z / slot order  */
+    uint32_t exact_order;       /* 1 = the reference's arithmetic, IEEE operation by operation: bit-identical to the CPU oracle.
+                                   0 = TOLERANCE MODE: same pairs, guards and summation order, but v_rcp_f32 / v_sqrt_f32
+                                   (1 ulp) instead of IEEE division / sqrt and re-associated products; within BASELINE.json's
+                                   1e-4 of the oracle after a frame (tests/test_gpu_tolerance_mode.py)                 */
     int32_t device_id;          /* HIP device ordinal (num_devices <= 1)                            */
     uint32_t flags;             /* SPH_FLAG_*                                                       */
     /* ---- ABI version 2 ---- */
@@ -91,6 +94,8 @@ typedef struct SphParams {
 #define SPH_FLAG_NO_OVERLAP 64u  /* z-slab mode, diagnostic: refresh the ghosts after the whole sub-step instead of behind its boundary pass */
 #define SPH_FLAG_FORCE_TWO_PASS 128u /* z-slab mode, diagnostic: two-pass sub-steps even with one slab (measures what the second pass costs) */
 #define SPH_FLAG_PEER_COPIES 32u /* multi-device context: move the halo with peer-to-peer device copies instead of RCCL */
+#define SPH_FLAG_TILE_LISTS 256u /* neighbour lists as LDS tile indices walked by k_velpos_tile (the default of exact_order = 0) also
+                                    with exact_order = 1: same bits, ~5 % slower there */
 #define SPH_FLAG_NO_GRAPHS 8u   /* diagnostic: sph_step issues its ~60 launches every frame instead of replaying a HIP graph */
 
 /* Values of the uniforms the reference pushes through ShaderIDs.cs:5-32. */

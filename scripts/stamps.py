@@ -1,4 +1,6 @@
-"""Diagnostic: per-brick phase durations of k_velpos_brick (build with SPH_HIPCC_EXTRA=-DSPH_STAMPS)."""
+"""Diagnostic: per-brick phase durations of k_velpos_brick (build with SPH_HIPCC_EXTRA=-DSPH_STAMPS=1) or of k_velpos_tile
+(-DSPH_STAMPS=2; phases: set-up + staging, entry rows + target, walk of thread 0, integrate + store of thread 0).
+  usage: python scripts/stamps.py [exact|tolerance]"""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -6,7 +8,7 @@ from sphfluidsimulation_amd import presets, _native as N
 from sphfluidsimulation_amd.simulation import SphFluidSimulation
 n = 16777216; R = presets.scene_bucket_resolution(n)
 pos0, vel0 = presets.dam_break(n, 0.8, 1)
-sim = SphFluidSimulation(particleNumber=n, bucketResolution=R, damFillRate=0.8).Start(pos0, vel0)
+sim = SphFluidSimulation(particleNumber=n, bucketResolution=R, damFillRate=0.8, exact_order=(sys.argv[1:] or ['exact'])[0] == 'exact').Start(pos0, vel0)
 sim.step_n(presets.bench_dt_frame(R), 4)
 nb = ((R + 3) // 4) ** 3
 buf = np.zeros((nb, 8), np.uint64)

@@ -18,7 +18,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIB_DIR, "libsph_hip.so")
 SOURCES = ["sph_engine.hip", "sph_kernels_grid.hip", "sph_kernels_sweep.hip", "sph_kernels_brick_density.hip", "sph_kernels_brick_velpos.hip", "sph_kernels_slab.hip", "sph_kernels_init.hip", "sph_kernels_mesh.hip", "sph_kernels_list.hip", "sph_kernels_selftest.hip", "sph_slab_frame.hip"]
-HEADERS = ["sph_internal.hpp", "sph_sweep_common.hpp", "sph_fastdiv.hpp", "sph_context.hpp", "sph_brick_impl.inc", os.path.join("..", "..", "include", "sph_hip.h")]
+HEADERS = ["sph_internal.hpp", "sph_sweep_common.hpp", "sph_list_common.hpp", "sph_fastdiv.hpp", "sph_context.hpp", "sph_brick_impl.inc", os.path.join("..", "..", "include", "sph_hip.h")]
 FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
     "-ffp-contract=off", "-fno-fast-math", "-fhip-fp32-correctly-rounded-divide-sqrt",

@@ -58,6 +58,7 @@ void refresh_scalars(SphContext *c)
     d.h9 = dv.effective_radius9;
     d.h2_up = nextafterf((float)((double)d.h * (double)d.h * (1.0 + 1e-5)), INFINITY);
     d.c_poly6 = 315.0f / (64.0f * PI);                        // Density.compute:23
+    d.w_scale = (float)((double)dv.particle_mass * (double)d.c_poly6 / (double)dv.effective_radius9);
     d.c_over_h6 = (45.0f / PI) / dv.effective_radius6;        // VelPos.compute:34,37,41,43
     d.viscosity = p.viscosity;
     d.gas_const = p.gas_constant;
@@ -69,6 +70,8 @@ void refresh_scalars(SphContext *c)
     d.gz = p.gravity[2];
     d.use_bricks = (p.flags & SPH_FLAG_NO_TILING) ? 0u : 1u;
     d.prec = p.precision;
+    d.fast = p.exact_order == 0u ? 1u : 0u;
+    d.nl_tile = (d.fast || (p.flags & SPH_FLAG_TILE_LISTS)) ? 1u : 0u;
     // neighbour lists: skin = nl_skin_frac * h; pre-filter radius (h + skin)^2 rounded up like h2_up; a brick is calm
     // while its relative-displacement bound stays below 90 % of the skin (the rest absorbs fp32 rounding of the bound)
     c->nl_enabled = d.use_bricks && !(p.flags & SPH_FLAG_NO_LISTS) && d.R <= 256u && !c->nl_unavailable;
@@ -101,7 +104,7 @@ static int validate(SphContext *ctx, const SphParams *p)
     if (p->substeps == 0 || p->substeps > 1000) return fail(ctx, SPH_E_INVALID_ARG, "substeps out of range");
     if (!(p->dt_divisor > 0.0f)) return fail(ctx, SPH_E_INVALID_ARG, "dt_divisor must be > 0");
     if (p->precision > 1) return fail(ctx, SPH_E_UNSUPPORTED, "precision %u not supported (0 = fp32, 1 = fp16 positions)", p->precision);
-    if (p->exact_order != 1) return fail(ctx, SPH_E_UNSUPPORTED, "exact_order=0 (fast mode) is not built in this version");
+    if (p->exact_order > 1) return fail(ctx, SPH_E_INVALID_ARG, "exact_order must be 0 (tolerance mode) or 1");
     if (p->num_devices > 8) return fail(ctx, SPH_E_INVALID_ARG, "num_devices %u > 8", p->num_devices);
     if (p->halo_planes > 128) return fail(ctx, SPH_E_INVALID_ARG, "halo_planes %u > 128", p->halo_planes);
     if (!(p->list_skin >= 0.0f && p->list_skin <= 1.0f)) return fail(ctx, SPH_E_INVALID_ARG, "list_skin must be in [0, 1]");

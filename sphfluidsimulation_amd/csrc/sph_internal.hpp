@@ -32,6 +32,7 @@ struct Dev {
     float mass, h, h2, h9;
     float h2_up;           // h^2 * (1 + 1e-5): conservative pre-filter for |r| < h
     float c_poly6;         // 315/(64*pi)           Density.compute:23
+    float w_scale;         // tolerance mode: mass * c_poly6 / h9 in one factor (Density.compute:26, :54)
     float c_over_h6;       // (45/pi)/h^6           VelPos.compute:37,43
     float viscosity, gas_const, rest_density, stiffness, damping;
     float gx, gy, gz;
@@ -42,6 +43,8 @@ struct Dev {
     uint32_t use_bricks;   // 1: LDS-tiled brick kernels + queue; 0: per-target kernels on global memory
     Soa cur, nxt;
     uint32_t prec;         // SphParams.precision: 0 = fp32 positions, 1 = fp16 cell-relative positions
+    uint32_t fast;         // SphParams.exact_order == 0: tolerance mode (hardware reciprocal / square root, see pair_fast)
+    uint32_t nl_tile;      // the brick kernels record lists of LDS tile indices and k_velpos_tile walks them (sph_list_common.hpp)
     uint32_t *cellkey;     // precision 1: reference cell of every slot, (cx+2) | (cy+2) << 10 | (cz+2) << 20; the cell the particle
                            //   was in when the slot was assigned (grid build / upload), fixed for a whole frame like `id`
     uint32_t *cellkey_nxt; // written by the reorder, swapped with cellkey after a grid build
@@ -303,6 +306,7 @@ void launch_density(const Dev &d, hipStream_t s);     // sph_kernels_brick.hip (
 void launch_velpos(const Dev &d, hipStream_t s, hipEvent_t list_begin = nullptr, hipEvent_t list_end = nullptr);
 void launch_list_prepare(const Dev &d, hipStream_t s);  // sph_kernels_list.hip: which bricks may use their lists
 void launch_frame_report(const Dev &d, unsigned long long *report, bool lists_in_use, hipStream_t s);   // sph_kernels_list.hip
+void launch_velpos_tile_lists(const Dev &d, hipStream_t s, hipEvent_t list_begin = nullptr, hipEvent_t list_end = nullptr);  // sph_kernels_brick_density.hip
 void launch_velpos_lists(const Dev &d, hipStream_t s, hipEvent_t list_begin = nullptr, hipEvent_t list_end = nullptr);  // sph_kernels_list.hip: the targets of those bricks, cur -> nxt
 
 

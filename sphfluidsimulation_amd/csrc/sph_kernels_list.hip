@@ -18,7 +18,7 @@
 // Everything else -- bricks that are not calm, targets failing (2), bricks with an unlistable target -- takes the
 // scanning kernels exactly as without lists.  Out-of-range entries contribute exact zeros (VelPos.compute:37,43 and
 // the "wild" guard of sph_kernels_sweep.hip), so which path served a target does not change a bit of the result.
-#include "sph_sweep_common.hpp"
+#include "sph_list_common.hpp"
 
 namespace sph {
 
@@ -137,66 +137,8 @@ __global__ void __launch_bounds__(kBlock) k_brick_activity(Dev d, int nbx, int n
     if (my_pos != 0xFFFFFFFFu) d.active_list[s_act[1] + my_pos] = (uint32_t)b;
 }
 
-// Hands the flagged targets of a block to the generic queue with ONE atomic on the queue counter (every thread of the
-// block must call it).  ~1 % of the targets fail condition (2) in a sub-step, i.e. nearly every wave holds one: an
-// atomic per lane, or even per wave, on that single address would serialise the launch (~3 ns each).
-__device__ __forceinline__ void enqueue_block(const Dev &d, bool pred, uint32_t slot, uint32_t *s_cnt, uint32_t *queue,
-                                              int counter)
-{
-    if (threadIdx.x == 0) s_cnt[0] = 0;
-    __syncthreads();
-    uint32_t k = 0;
-    if (pred) k = atomicAdd(&s_cnt[0], 1u);
-    __syncthreads();
-    if (threadIdx.x == 0 && s_cnt[0]) s_cnt[1] = (uint32_t)atomicAdd(&d.counters[counter], (unsigned long long)s_cnt[0]);
-    __syncthreads();
-    if (pred) queue[s_cnt[1] + k] = slot;
-}
-
-// Where a target stands against the stencil its list was recorded for.
-struct ListTarget {
-    float qx, qy, qz;      // where it was binned
-    float px, py, pz;      // where it is now, VelPos.compute:57
-    int c0x, c0y, c0z;     // recorded stencil centre (its bin)
-    int shx, shy, shz;     // current cell - c0
-    uint32_t mask;         // recorded stencil cells (0..26) that are still in the stencil
-};
-
-template <int PREC = -1>
-__device__ __forceinline__ ListTarget list_target(const Dev &d, uint32_t s)
-{
-    ListTarget t;
-    const int R = (int)d.R;
-    const Pos3 pb = load_binned<PREC>(d, s), pc = load_pos<PREC>(d, d.cur, s);
-    t.qx = pb.x; t.qy = pb.y; t.qz = pb.z;
-    t.px = pc.x; t.py = pc.y; t.pz = pc.z;
-    t.c0x = cell_coord(t.qx, d.Rm1, R); t.c0y = cell_coord(t.qy, d.Rm1, R); t.c0z = cell_coord(t.qz, d.Rm1, R);
-    t.shx = cell_coord(t.px, d.Rm1, R) - t.c0x;                                  // :58
-    t.shy = cell_coord(t.py, d.Rm1, R) - t.c0y;
-    t.shz = cell_coord(t.pz, d.Rm1, R) - t.c0z;
-    t.mask = 0x7FFFFFFu;
-    return t;
-}
-
-__device__ __forceinline__ bool one_cell_away(const ListTarget &t)
-{
-    return t.shx >= -1 && t.shx <= 1 && t.shy >= -1 && t.shy <= 1 && t.shz >= -1 && t.shz <= 1;
-}
-
-// offsets {-1,0,1} of the recorded stencil that lie within one cell of the shifted centre, per axis -> cell mask
-__device__ __forceinline__ uint32_t shifted_mask(const ListTarget &t)
-{
-    const uint32_t ax = t.shx > 0 ? 6u : (t.shx < 0 ? 3u : 7u), ay = t.shy > 0 ? 6u : (t.shy < 0 ? 3u : 7u),
-                   az = t.shz > 0 ? 6u : (t.shz < 0 ? 3u : 7u);
-    uint32_t mask = 0;
-#pragma unroll
-    for (int code = 0; code < 27; code++)
-        if (((ax >> (code / 9)) & (ay >> ((code / 3) % 3)) & (az >> (code % 3))) & 1u) mask |= 1u << code;
-    return mask;
-}
-
 // The pair sums of VelPos.compute:67-98 from the recorded list of slot s (n entries), then :100-157.
-template <int PREC>
+template <int PREC, bool FAST>
 __device__ __forceinline__ void walk_list_and_integrate(const Dev &d, uint32_t s, uint32_t n, uint32_t mask, bool live,
                                                         float pix, float piy, float piz)
 {
@@ -240,6 +182,14 @@ __device__ __forceinline__ void walk_list_and_integrate(const Dev &d, uint32_t s
             a0 = b0; a1 = b1;
             continue;
 #endif
+            if (FAST) {                                                          // tolerance mode (compile time)
+                pair_fast(d, pix - a0.x, piy - a0.y, piz - a0.z, a0.rho, a0.vx, a0.vy, a0.vz, vix, viy, viz, p_i, f, a0.take);
+                pair_fast(d, pix - a1.x, piy - a1.y, piz - a1.z, a1.rho, a1.vx, a1.vy, a1.vz, vix, viy, viz, p_i, f,
+                          e + 1 < n && a1.take);
+                a0 = b0;
+                a1 = b1;
+                continue;
+            }
             // (the list kernels never run in a wild launch: nl_blocked)
             const PairPre q0 = pair_pre<true>(d, pix - a0.x, piy - a0.y, piz - a0.z, a0.rho, a0.vx, a0.vy, a0.vz, vix, viy, viz,
                                               p_i, a0.take);                     // :86-95
@@ -262,7 +212,7 @@ __device__ __forceinline__ void walk_list_and_integrate(const Dev &d, uint32_t s
 // (mean 17.8 entries, mean of the per-wave maxima 24.7: scripts/list_balance.py); dealing the slots of a workgroup to its
 // waves by list length cuts the trips by 19 % but ran 20-40 % SLOWER, stable or not (round 2): lanes that are no longer
 // spatial neighbours gather 64 unrelated cache lines per instruction.  Consecutive slots per wave stay.
-template <int PREC>
+template <int PREC, bool FAST>
 __global__ void __launch_bounds__(kListBlock, SPH_LIST_MINWAVES) k_velpos_list(Dev d)
 {
     __shared__ uint32_t s_queue[2];
@@ -287,6 +237,8 @@ __global__ void __launch_bounds__(kListBlock, SPH_LIST_MINWAVES) k_velpos_list(D
     const uint32_t s = live ? s_raw : 0u;
     ListTarget t = list_target<PREC>(d, s);
     uint32_t n = d.nl_cnt[s];
+    if (n & kNlTileFormat) live = false;           // a list of tile indices: k_velpos_tile walks it
+    n &= kNlCountMask;
     const uint32_t key = bucket_key(d, t.qx, t.qy, t.qz);                        // the bin, Bucket.compute:26-29
     live = live && key < d.num_cells;                                            // limbo: queued by the brick kernel
     if (d.ghost && d.ghost[s]) live = false;       // z-slab mode: ghosts are candidates only, their owner integrates them
@@ -304,7 +256,7 @@ __global__ void __launch_bounds__(kListBlock, SPH_LIST_MINWAVES) k_velpos_list(D
     if (live && (t.c0z + t.shz < d.zt_lo || t.c0z + t.shz > d.zt_hi)) atomicAdd(&d.counters[kCntHaloViolation], 1ull);
     enqueue_block(d, hand_over, s, s_queue, d.queue2, kCntQueue2);
     if (!live) n = 0;
-    walk_list_and_integrate<PREC>(d, s, n, t.mask, live, t.px, t.py, t.pz);
+    walk_list_and_integrate<PREC, FAST>(d, s, n, t.mask, live, t.px, t.py, t.pz);
     stat_add(d, kStatListed, live ? 1ull : 0ull);
     stat_add(d, kStatListEntries, (unsigned long long)n);
 }
@@ -405,8 +357,13 @@ void launch_velpos_lists(const Dev &d, hipStream_t s, hipEvent_t list_begin, hip
     if (list_begin) (void)hipEventRecord(list_begin, s);     // the events bracket k_velpos_list alone (bench.py roofline)
     const uint32_t blocks = d.pass_mode == 1u ? (d.zone_blocks[0] + d.zone_blocks[1] ? d.zone_blocks[0] + d.zone_blocks[1] : 1u)
                                               : cdiv(d.count, kListBlock);
-    if (d.prec == 0u) hipLaunchKernelGGL(k_velpos_list<0>, dim3(blocks), dim3(kListBlock), 0, s, d);
-    else hipLaunchKernelGGL(k_velpos_list<1>, dim3(blocks), dim3(kListBlock), 0, s, d);
+    if (d.prec == 0u) {
+        if (d.fast) hipLaunchKernelGGL((k_velpos_list<0, true>), dim3(blocks), dim3(kListBlock), 0, s, d);
+        else hipLaunchKernelGGL((k_velpos_list<0, false>), dim3(blocks), dim3(kListBlock), 0, s, d);
+    } else {
+        if (d.fast) hipLaunchKernelGGL((k_velpos_list<1, true>), dim3(blocks), dim3(kListBlock), 0, s, d);
+        else hipLaunchKernelGGL((k_velpos_list<1, false>), dim3(blocks), dim3(kListBlock), 0, s, d);
+    }
     if (list_end) (void)hipEventRecord(list_end, s);
     if (d.nl_still) return;                        // first sub-step: nobody has changed cell, nothing was handed over
     const uint32_t g = cdiv(d.count, kBlock);

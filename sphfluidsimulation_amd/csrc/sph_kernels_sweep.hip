@@ -49,7 +49,7 @@ __device__ __forceinline__ uint32_t density_target(const Dev &d, uint32_t s)
                     const Pos3 pj = load_pos(d, d.cur, j);
                     const float rx = pix - pj.x, ry = piy - pj.y, rz = piz - pj.z;
                     const float r2 = (rx * rx + ry * ry) + rz * rz;              // Density.compute:24
-                    rho += density_term_r2(d, r2);
+                    rho += d.fast ? density_term_r2<true>(d, r2) : density_term_r2<false>(d, r2);
                     if (RECORD && r2 < d.h2_list) {                              // superset of |r| < h + skin
                         if (gn < d.nl_cap) nl_row[gn * kWave] = (code << kNlSlotBits) | j;
                         gn++;

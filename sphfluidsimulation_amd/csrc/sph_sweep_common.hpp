@@ -39,9 +39,12 @@ __device__ __forceinline__ CellRange cell_range(const Dev &d, int jx, int jy, in
 }
 
 // Density.compute:22-27 W() times _ParticleMass (:54), from abs_r2 = (rx*rx + ry*ry) + rz*rz (:24)
+// FAST (tolerance mode, SphParams.exact_order = 0): mass * c / h^9 is one factor, no division.
+template <bool FAST = false>
 __device__ __forceinline__ float density_term_r2(const Dev &d, float abs_r2)
 {
     const float diff_r2 = d.h2 - abs_r2;                                         // :25
+    if (FAST) return 0.0f < diff_r2 ? d.w_scale * ((diff_r2 * diff_r2) * diff_r2) : 0.0f;
     const float w = 0.0f < diff_r2 ? d.c_poly6 * ((diff_r2 * diff_r2) * diff_r2) / d.h9 : 0.0f; // :26
     return d.mass * w;                                                           // :54
 }
@@ -140,11 +143,45 @@ __device__ __forceinline__ void pair_force_two(const PairPre &a, const PairPre &
     }
 }
 
+// TOLERANCE MODE (SphParams.exact_order = 0): the same pair, the same guards and the same summation order, with the seven
+// IEEE divisions replaced by two hardware reciprocals (v_rcp_f32, 1 ulp) and sqrt by v_sqrt_f32 (1 ulp), products
+// re-associated so that each sum takes one select and three multiply-adds.  ~45 VALU instructions per pair instead of ~135;
+// relative error of a pair term ~1e-6, the parity bar of this mode is BASELINE.json's 1e-4 (tests/test_gpu_tolerance_mode.py).
+// No "wild" detour: extreme operands give inf / NaN here as in IEEE arithmetic, not necessarily in the same lanes.
+__device__ __forceinline__ void pair_fast(const Dev &d, float rx, float ry, float rz, float rho_j, float vjx, float vjy,
+                                          float vjz, float vix, float viy, float viz, float p_i, Force &f, bool take)
+{
+    const float epsilon = 1e-6f;                                                 // :5
+    const float h = d.h;
+    const float r2 = __builtin_fmaf(rz, rz, __builtin_fmaf(ry, ry, rx * rx));
+    const float abs_r = __builtin_amdgcn_sqrtf(r2);                              // :35, :42
+    const float rinv = __builtin_amdgcn_rcpf(abs_r), rrho = __builtin_amdgcn_rcpf(rho_j);
+    const float diff_r = h - abs_r;                                              // :36
+    const bool ok = take && (rho_j > epsilon);                                   // :91
+    const bool sel_p = ok && (epsilon < diff_r) && (epsilon < abs_r);            // :37
+    const bool sel_v = ok && (abs_r < h);                                        // :43
+    const float p_j = d.gas_const * (rho_j - d.rest_density);                    // :87
+    const float cd = d.c_over_h6 * diff_r;                                       // shared by :37 (x diff_r^2 / |r|) and :43
+    const float kp = ((p_i + p_j) * (0.5f * rrho)) * ((cd * (diff_r * diff_r)) * rinv);   // :93 x :37
+    const float kv = cd * rrho;                                                  // :94 x :43
+    const float sp = sel_p ? kp : 0.0f, sv = sel_v ? kv : 0.0f;
+    f.px = __builtin_fmaf(sp, rx, f.px);
+    f.py = __builtin_fmaf(sp, ry, f.py);
+    f.pz = __builtin_fmaf(sp, rz, f.pz);
+    f.vx = __builtin_fmaf(sv, vjx - vix, f.vx);
+    f.vy = __builtin_fmaf(sv, vjy - viy, f.vy);
+    f.vz = __builtin_fmaf(sv, vjz - viz, f.vz);
+}
+
 // One candidate; `literal` = the launch is wild (wave-uniform).
 __device__ __forceinline__ void pair_force_vals(const Dev &d, float rx, float ry, float rz, float rho_j,
                                                 float vjx, float vjy, float vjz, float vix, float viy,
                                                 float viz, float p_i, Force &f, bool take, bool literal)
 {
+    if (d.fast) {                                  // tolerance mode (launch-uniform)
+        pair_fast(d, rx, ry, rz, rho_j, vjx, vjy, vjz, vix, viy, viz, p_i, f, take);
+        return;
+    }
     if (literal) {
         pair_finish<false>(pair_pre<false>(d, rx, ry, rz, rho_j, vjx, vjy, vjz, vix, viy, viz, p_i, take), f);
         return;
