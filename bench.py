@@ -106,13 +106,11 @@ def committed_csv(suffix, kernel_substr):
     """Row of the newest committed profiles/*<suffix> for the kernel (rocprofv3 --pmc runs of this command at 16 777 216)."""
     import csv
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*" + suffix)))
-    if not files:
-        return None, None
-    for row in csv.DictReader(open(files[-1])):
-        name = row["kernel"]
-        if kernel_substr + "<" in name or kernel_substr + "(" in name:      # (k_velpos_list, not k_velpos_list_changers)
-            return row, os.path.relpath(files[-1], ROOT) + " (16 777 216 particles)"
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*" + suffix)), reverse=True):   # newest file that has the kernel
+        for row in csv.DictReader(open(f)):
+            name = row["kernel"]
+            if kernel_substr + "<" in name or kernel_substr + "(" in name:  # (k_velpos_list, not k_velpos_list_changers)
+                return row, os.path.relpath(f, ROOT) + " (16 777 216 particles)"
     return None, None
 
 
@@ -223,6 +221,7 @@ def main():
     sim.synchronize()
     mesh_ms = (time.perf_counter() - tm) * 1e3 / 20
     extras = {}
+    tol_state = None
     if not a.no_extras:
         # the dam collapses: cells fill up, the calm boxes the neighbour lists live on shrink (never part of `value`)
         late_to = 300
@@ -250,6 +249,37 @@ def main():
         extras["s1_variant"] = {"substeps": 1, "ms_per_step": e1 * 1e3 / a.steps, "particle_steps_per_s": n * a.steps / e1}
         sim.substeps = 5
         sim.set_params()
+        if a.mode == "exact" and a.precision == 0:
+            # the tolerance mode (SphParams.exact_order = 0; parity bar 1e-4, BASELINE.json north_star), same workload, same
+            # protocol: its own engine, warm-up, then the same number of frames (never part of `value`)
+            sim.OnDestroy()
+            tol = SphFluidSimulation(particleNumber=n, bucketResolution=R, damFillRate=fill, viscosity=0.01, restDensity=1.5,
+                                     gasConstant=150.0, stiffnessCoefficient=5000.0, dampingCoefficient=10.0, device_id=0,
+                                     profile=True, exact_order=False).Start(pos0, vel0)
+            tol_state = None
+            if not a.no_cpu_baseline:
+                for _ in range(CPU_FRAMES):
+                    tol.Update(dt_frame)
+                tol_state = tol.download()
+                tol.upload(pos0, vel0)
+            tol.step_n(dt_frame, warm)
+            tol.synchronize()
+            tol.reset_stats()
+            tt = time.perf_counter()
+            tol.step_n(dt_frame, a.steps)
+            tol.synchronize()
+            et = time.perf_counter() - tt
+            ts = tol.stats()
+            extras["tolerance_mode"] = {
+                "mode": "SphParams.exact_order = 0: v_rcp_f32 / v_sqrt_f32 instead of IEEE division / sqrt, lists of LDS tile indices",
+                "ms_per_step": et * 1e3 / a.steps, "particle_steps_per_s": n * a.steps / et, "parity_bar": "1e-4",
+                "kernel": "k_velpos_tile", "kernel_ms": ts["ms_velpos_list"] / max(ts["launches_velpos_list"], 1),
+                "passes_ms": {"grid": ts["ms_grid"] / max(ts["launches_grid"], 1), "density": ts["ms_density"] / max(ts["launches_density"], 1),
+                              "velpos": ts["ms_velpos"] / max(ts["launches_velpos"], 1)}}
+            tol.OnDestroy()
+            sim = SphFluidSimulation(particleNumber=n, bucketResolution=R, damFillRate=fill, viscosity=0.01, restDensity=1.5,
+                                     gasConstant=150.0, stiffnessCoefficient=5000.0, dampingCoefficient=10.0, device_id=0,
+                                     profile=True, precision=a.precision).Start(pos0, vel0)
     # boundary cost when the caller hands over HOST arrays every frame (never part of `value`)
     t1 = time.perf_counter()
     sim.upload(pos0, vel0)
@@ -261,7 +291,8 @@ def main():
     pbar = st["candidates_density"] / n
     vel_ms = st["ms_velpos"] / max(st["launches_velpos"], 1)           # whole sub-step (all its kernels)
     listed = st["launches_velpos_list"] > 0
-    kernel = "k_velpos_list" if listed else "k_velpos_brick"
+    # exact mode walks lists of global slots (k_velpos_list); tolerance mode lists of LDS tile indices (k_velpos_tile)
+    kernel = ("k_velpos_tile" if a.mode == "tolerance" else "k_velpos_list") if listed else "k_velpos_brick"
     kernel_ms = st["ms_velpos_list"] / st["launches_velpos_list"] if listed else vel_ms
     bytes_substep = BYTES_PER_SUBSTEP if a.precision == 0 else 40     # (6 + 12 + 4) R + (6 + 12) W with fp16 positions
     bytes_step = (32 + 52 * 5) if a.precision == 0 else (20 + 40 * 5)
@@ -318,6 +349,14 @@ def main():
         out["parity_bar"] = "bit-identical (0.0)" if a.precision == 0 and a.mode == "exact" else "1e-4"
         out["parity_max_abs_diff"] = {"pos": float(np.abs(parity_state[0] - po).max()), "vel": float(np.abs(parity_state[1] - vo).max()),
                                       "rho": float(np.abs(parity_state[2] - ro).max())}
+        if "tolerance_mode" in out and tol_state is not None:
+            vs = max(1.0, float(np.abs(vo[:, :3]).max()))
+            ev = np.abs(tol_state[1][:, :3].astype(np.float64) - vo[:, :3]).max(1) / vs
+            out["tolerance_mode"]["parity_frames"] = CPU_FRAMES
+            out["tolerance_mode"]["parity_vs_oracle"] = {
+                "pos_max_abs": float(np.abs(tol_state[0][:, :3] - po[:, :3]).max()), "vel_max_rel": float(ev.max()),
+                "vel_p99.99_rel": float(np.percentile(ev, 99.99)),
+                "rho_max_rel": float((np.abs(tol_state[2].astype(np.float64) - ro) / np.maximum(np.abs(ro), 1e-6)).max())}
     sim.OnDestroy()
     print(json.dumps(out), flush=True)
 

@@ -1,11 +1,13 @@
 # HBM traffic of every kernel: FETCH_SIZE and WRITE_SIZE in separate --pmc passes (MI355X_MICROARCH.md, HBM section)
+#   usage (on the GPU box): bash scripts/gpu_traffic.sh TAG ["extra bench.py args"]
 TAG=${1:-r01}
+ARGS=${2:-}
 mkdir -p gpurun_out
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 for C in FETCH_SIZE WRITE_SIZE; do
-  timeout -k 10 600 rocprofv3 --pmc $C --kernel-trace --output-format csv -d gpurun_out/pmc_${TAG}_$C -- python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-extras > gpurun_out/pmc_${TAG}_$C.log 2>&1 || exit 1
+  timeout -k 10 600 rocprofv3 --pmc $C --kernel-trace --output-format csv -d gpurun_out/pmc_${TAG}_$C -- python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-extras $ARGS > gpurun_out/pmc_${TAG}_$C.log 2>&1 || exit 1
 done
-timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${TAG} -- python3 bench.py --no-cpu-baseline --no-extras > gpurun_out/prof_${TAG}.log 2>&1 || exit 1
+timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${TAG} -- python3 bench.py --no-cpu-baseline --no-extras $ARGS > gpurun_out/prof_${TAG}.log 2>&1 || exit 1
 python3 - <<PY
 import csv, glob, collections
 out = collections.defaultdict(dict)

@@ -217,6 +217,7 @@ __global__ void __launch_bounds__(kListBlock, SPH_LIST_MINWAVES) k_velpos_list(D
 {
     __shared__ uint32_t s_queue[2];
     if (nl_blocked(d)) return;                     // the scanning kernels take everything
+    if (d.nl_tile && d.counters[kCntGlobalLists] == 0ull) return;   // every list of the frame holds tile indices: k_velpos_tile's
     uint32_t s_base = xcd_contiguous_block() * kListBlock, s_raw = s_base + threadIdx.x;
     bool live = s_raw < d.count;
     if (d.pass_mode == 1u) {

@@ -57,6 +57,7 @@ __device__ __forceinline__ uint32_t density_target(const Dev &d, uint32_t s)
                 }
             }
     if (RECORD) {
+        d.counters[kCntGlobalLists] = 1ull;
         if (gn <= d.nl_cap) d.nl_cnt[s] = (uint16_t)gn;
         else {                                                                   // list too long: its brick keeps scanning
             const uint32_t ux = (uint32_t)(ix < 0 ? 0 : (ix > R - 1 ? R - 1 : ix)), uy = (uint32_t)(iy < 0 ? 0 : (iy > R - 1 ? R - 1 : iy)),

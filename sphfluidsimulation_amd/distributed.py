@@ -162,7 +162,7 @@ class SlabSimulation:
                  viscosity: float = 0.01, restDensity: float = 1.5, gasConstant: float = 150.0,
                  stiffnessCoefficient: float = 5000.0, dampingCoefficient: float = 10.0, device_id: int = 0,
                  halo_w: int = 2, capacity_factor: float = 1.6, profile: bool = False, group=None,
-                 transport: str = "auto", precision: int = 0):
+                 transport: str = "auto", precision: int = 0, exact_order: bool = True):
         self.rank, self.world = rank, world
         self.halo_w = halo_w
         self.capacity_factor = capacity_factor
@@ -180,6 +180,7 @@ class SlabSimulation:
         p.device_id = device_id
         p.halo_planes = int(halo_w)
         p.precision = int(precision)                  # 1: fp16 position records (BASELINE config 5), see include/sph_hip.h
+        p.exact_order = 1 if exact_order else 0       # 0: tolerance mode (hardware reciprocal / sqrt, parity bar 1e-4)
         p.flags = (N.SPH_FLAG_PROFILE if profile else 0) | int(__import__('os').environ.get('SPH_SLAB_FLAGS', '0'))   # (diagnostic flags, e.g. 64 / 128)
         self._params = p
         self.R = int(bucketResolution)
@@ -345,7 +346,8 @@ def bench_main(a, n, R, fill, dt_frame, rank, world, local_rank):
         dist.init_process_group("gloo", rank=rank, world_size=world)
     pos0, vel0 = presets.dam_break(n, fill, a.seed)
     sim = SlabSimulation(rank, world, n, R, fill, 0.01, 1.5, 150.0, 5000.0, 10.0, device_id=local_rank,
-                         halo_w=2, profile=True, transport=transport).Start(pos0, vel0)
+                         halo_w=2, profile=True, transport=transport, precision=getattr(a, "precision", 0),
+                         exact_order=getattr(a, "mode", "exact") == "exact").Start(pos0, vel0)
     del pos0, vel0
     ctl = sim.control
     warm = max(a.warmup, 1)
@@ -375,7 +377,8 @@ def bench_main(a, n, R, fill, dt_frame, rank, world, local_rank):
         "metric": "particle-steps/s", "value": value, "unit": "particle-steps/s", "n_gpus": world, "steps": a.steps,
         "warmup": warm, "ms_per_step": elapsed * 1e3 / a.steps, "higher_is_better": True, "scaling": "strong",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "", "particles": n, "bucket_resolution": R, "substeps": 5, "mode": "exact_order",
+        "config": {"workload": "", "particles": n, "bucket_resolution": R, "substeps": 5,
+                   "mode": "exact_order" if getattr(a, "mode", "exact") == "exact" else "tolerance 1e-4 (v_rcp_f32 / v_sqrt_f32)",
                    "decomposition": f"{world} z-slabs, halo {st['halo_planes']} planes, in-library neighbour exchange "
                                     f"({sim.transport}), ghost refreshes overlapped with the interior targets of each sub-step, "
                                     f"torch.distributed/gloo control plane"},
