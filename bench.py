@@ -55,6 +55,7 @@ def parse():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--mode", choices=["exact", "tolerance"], default="exact",
                     help="exact: bit-identical to the CPU oracle (SphParams.exact_order = 1); tolerance: hardware reciprocal / sqrt, parity bar 1e-4")
+    ap.add_argument("--global-lists", action="store_true", help="diagnostic: lists of global slots gathered through L1 by k_velpos_list (SPH_FLAG_GLOBAL_LISTS)")
     ap.add_argument("--precision", type=int, default=0, help="1: positions stored as fp16 cell offsets (BASELINE config 5), arithmetic fp32")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the S = 1 variant and the late-phase (frames 281-300) figure")
@@ -182,7 +183,7 @@ def main():
     sim = SphFluidSimulation(particleNumber=n, bucketResolution=R, damFillRate=fill, viscosity=0.01,
                              restDensity=1.5, gasConstant=150.0, stiffnessCoefficient=5000.0,
                              dampingCoefficient=10.0, device_id=0, profile=True, precision=a.precision,
-                             exact_order=a.mode == "exact").Start(pos0, vel0)
+                             exact_order=a.mode == "exact", tile_lists=not a.global_lists).Start(pos0, vel0)
 
     # GPU result after CPU_FRAMES frames, checked against the CPU baseline run below; then start over for the timing
     warm = a.warmup
@@ -291,8 +292,8 @@ def main():
     pbar = st["candidates_density"] / n
     vel_ms = st["ms_velpos"] / max(st["launches_velpos"], 1)           # whole sub-step (all its kernels)
     listed = st["launches_velpos_list"] > 0
-    # exact mode walks lists of global slots (k_velpos_list); tolerance mode lists of LDS tile indices (k_velpos_tile)
-    kernel = ("k_velpos_tile" if a.mode == "tolerance" else "k_velpos_list") if listed else "k_velpos_brick"
+    # lists of LDS tile indices (k_velpos_tile); --global-lists: lists of global slots (k_velpos_list)
+    kernel = ("k_velpos_list" if a.global_lists else "k_velpos_tile") if listed else "k_velpos_brick"
     kernel_ms = st["ms_velpos_list"] / st["launches_velpos_list"] if listed else vel_ms
     bytes_substep = BYTES_PER_SUBSTEP if a.precision == 0 else 40     # (6 + 12 + 4) R + (6 + 12) W with fp16 positions
     bytes_step = (32 + 52 * 5) if a.precision == 0 else (20 + 40 * 5)

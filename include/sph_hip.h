@@ -94,8 +94,9 @@ typedef struct SphParams {
 #define SPH_FLAG_NO_OVERLAP 64u  /* z-slab mode, diagnostic: refresh the ghosts after the whole sub-step instead of behind its boundary pass */
 #define SPH_FLAG_FORCE_TWO_PASS 128u /* z-slab mode, diagnostic: two-pass sub-steps even with one slab (measures what the second pass costs) */
 #define SPH_FLAG_PEER_COPIES 32u /* multi-device context: move the halo with peer-to-peer device copies instead of RCCL */
-#define SPH_FLAG_TILE_LISTS 256u /* neighbour lists as LDS tile indices walked by k_velpos_tile (the default of exact_order = 0) also
-                                    with exact_order = 1: same bits, ~5 % slower there */
+#define SPH_FLAG_GLOBAL_LISTS 256u /* diagnostic: the brick kernels record lists of global slots and k_velpos_list gathers the
+                                      candidates through L1/L2 (rounds 1-2) instead of lists of LDS tile indices walked by
+                                      k_velpos_tile; same bits, slower */
 #define SPH_FLAG_NO_GRAPHS 8u   /* diagnostic: sph_step issues its ~60 launches every frame instead of replaying a HIP graph */
 
 /* Values of the uniforms the reference pushes through ShaderIDs.cs:5-32. */

@@ -23,7 +23,7 @@ SPH_FLAG_LISTS_ALWAYS = 16
 SPH_FLAG_PEER_COPIES = 32
 SPH_FLAG_NO_OVERLAP = 64
 SPH_FLAG_FORCE_TWO_PASS = 128
-SPH_FLAG_TILE_LISTS = 256
+SPH_FLAG_GLOBAL_LISTS = 256
 SPH_COMM_ID_BYTES = 128
 SPH_SLAB_UPDATE_RHO = 0
 SPH_SLAB_UPDATE_POSVEL = 1

@@ -71,7 +71,7 @@ void refresh_scalars(SphContext *c)
     d.use_bricks = (p.flags & SPH_FLAG_NO_TILING) ? 0u : 1u;
     d.prec = p.precision;
     d.fast = p.exact_order == 0u ? 1u : 0u;
-    d.nl_tile = (d.fast || (p.flags & SPH_FLAG_TILE_LISTS)) ? 1u : 0u;
+    d.nl_tile = (p.flags & SPH_FLAG_GLOBAL_LISTS) ? 0u : 1u;
     // neighbour lists: skin = nl_skin_frac * h; pre-filter radius (h + skin)^2 rounded up like h2_up; a brick is calm
     // while its relative-displacement bound stays below 90 % of the skin (the rest absorbs fp32 rounding of the bound)
     c->nl_enabled = d.use_bricks && !(p.flags & SPH_FLAG_NO_LISTS) && d.R <= 256u && !c->nl_unavailable;

@@ -195,7 +195,7 @@ __device__ __forceinline__ void walk_list_and_integrate(const Dev &d, uint32_t s
                                               p_i, a0.take);                     // :86-95
             const PairPre q1 = pair_pre<true>(d, pix - a1.x, piy - a1.y, piz - a1.z, a1.rho, a1.vx, a1.vy, a1.vz, vix, viy, viz,
                                               p_i, e + 1 < n && a1.take);
-            pair_force_two(q0, q1, f);
+            pair_force_two(d, q0, q1, f);
             a0 = b0;
             a1 = b1;
         }

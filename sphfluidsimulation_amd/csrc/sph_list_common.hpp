@@ -16,7 +16,7 @@ namespace sph {
 //                recorded by k_density_brick<RECORD>, walked by k_velpos_tile, which stages the same tile again -- the tile
 //                is a function of cell_start alone, and the grid is frozen for the frame (SphFluidSimulation.cs:98-102).
 // A list of global slots includes the target itself (the walk skips it, VelPos.compute:82); a list of tile indices does not.
-// Which format the brick kernel records: Dev::nl_tile (tolerance mode, or SPH_FLAG_TILE_LISTS) -- see DESIGN.md 4.
+// Which format the brick kernel records: Dev::nl_tile (tile indices unless SPH_FLAG_GLOBAL_LISTS) -- see DESIGN.md 4.
 constexpr uint32_t kNlTileFormat = 0x8000u, kNlCountMask = 0x7FFFu;
 constexpr uint32_t kNlTileIdxBits = 11;          // tiles hold <= 2048 listed particles
 

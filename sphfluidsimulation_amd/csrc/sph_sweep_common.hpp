@@ -130,13 +130,51 @@ __device__ __forceinline__ void pair_finish(const PairPre &q, Force &f)
     f.vz += q.ok ? uz : 0.0f;
 }
 
-// Two candidates (a then b: the reference's order) of a launch that is not "wild".
-__device__ __forceinline__ void pair_force_two(const PairPre &a, const PairPre &b, Force &f)
+// pair_finish<true> with the guards folded, for a launch that is not wild.  Every quantity that reaches a select is finite
+// here or is thrown away by it:
+//   * one select per sum on (ok && in_p) instead of three on in_p and three on ok: with in_p false the reference adds
+//     cp * 0 = +-0 (cp finite: ok), which leaves a sum that is never -0 unchanged, as adding +0 does; a quotient by
+//     |r| <= 1e-6 (inf, NaN) only ever reaches a select that drops it;
+//   * the guard of grad_W_vis (:43) folded into the select of its sum the same way (q_xyz finite: |dv| < 2e15, rho_j > 1e-6);
+//   * no v_div_fixup: inside the window of sph_fastdiv.hpp it only restores the sign of a zero quotient, and a zero
+//     quotient of either sign contributes +-0.
+__device__ __forceinline__ float div_shared_nofix(float a, const Recip &d)
+{
+    const float q0 = a * d.r;
+    const float e0 = __builtin_fmaf(-d.b, q0, a);
+    const float q1 = __builtin_fmaf(e0, d.r, q0);
+    const float e1 = __builtin_fmaf(-d.b, q1, a);
+    return __builtin_fmaf(e1, d.r, q1);
+}
+__device__ __forceinline__ void pair_finish_folded(const Dev &d, const PairPre &q, Force &f)
+{
+    const Recip ra = recip_refined(q.abs_r), rr = recip_refined(q.rho_j), r2 = recip_twice(rr);
+    const float gpx = div_shared_nofix(q.ngx, ra), gpy = div_shared_nofix(q.ngy, ra), gpz = div_shared_nofix(q.ngz, ra);
+    const float cp = div_shared_nofix(q.ncp, r2);
+    const float qx = div_shared_nofix(q.nvx, rr), qy = div_shared_nofix(q.nvy, rr), qz = div_shared_nofix(q.nvz, rr);
+    const float gv = d.c_over_h6 * (d.h - q.abs_r);                              // :43 without its guard
+    const bool sel_p = q.ok && q.in_p, sel_v = q.ok && (q.abs_r < d.h);
+    const float tx = cp * gpx, ty = cp * gpy, tz = cp * gpz;
+    const float ux = qx * gv, uy = qy * gv, uz = qz * gv;
+    f.px += sel_p ? tx : 0.0f;
+    f.py += sel_p ? ty : 0.0f;
+    f.pz += sel_p ? tz : 0.0f;
+    f.vx += sel_v ? ux : 0.0f;
+    f.vy += sel_v ? uy : 0.0f;
+    f.vz += sel_v ? uz : 0.0f;
+}
+
+// Two candidates (a then b: the reference's order) of a launch that is not "wild".  FOLDED: pair_finish_folded.
+template <bool FOLDED = false>
+__device__ __forceinline__ void pair_force_two(const Dev &d, const PairPre &a, const PairPre &b, Force &f)
 {
     const uint32_t ka = pair_min_key(a), kb = pair_min_key(b);
     if (__builtin_expect(__any((ka < kb ? ka : kb) < kMagKeyMin), 0)) {          // wave-uniform; practically never
         pair_finish<false>(a, f);
         pair_finish<false>(b, f);
+    } else if (FOLDED) {
+        pair_finish_folded(d, a, f);
+        pair_finish_folded(d, b, f);
     } else {
         pair_finish<true>(a, f);
         pair_finish<true>(b, f);

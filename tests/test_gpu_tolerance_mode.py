@@ -6,7 +6,7 @@ the reference's grid makes the result discontinuous in the positions, see tests/
 must still agree with each other BIT FOR BIT in this mode (they share the arithmetic and the order).
 
 The kernel this mode is built around, k_velpos_tile (lists of LDS tile indices), also runs with the reference's IEEE arithmetic
-(SPH_FLAG_TILE_LISTS): there it must be bit-identical to the oracle like every other route."""
+(the default list format): there it must be bit-identical to the oracle like every other route."""
 import numpy as np
 import pytest
 
@@ -88,7 +88,7 @@ def test_tolerance_mode_routes_agree_bit_for_bit():
 
 @pytest.mark.parametrize("n,R,frames", [(4096, 13, 10), (262144, 47, 6)])
 def test_tile_lists_with_exact_arithmetic_match_the_oracle(oracle, n, R, frames):
-    """k_velpos_tile + the tile-index lists with exact_order = 1 (SPH_FLAG_TILE_LISTS): bit-identical to the oracle, with
+    """k_velpos_tile + the tile-index lists with exact_order = 1 (the default list format): bit-identical to the oracle, with
     targets that change cell, over-full cells and one process split into slabs."""
     pos0, vel0 = presets.dam_break(n, 0.8, 2)
     vel0[:, :3] = np.random.default_rng(4).normal(0, 0.7, (n, 3)).astype(np.float32)
@@ -162,3 +162,32 @@ def test_tolerance_mode_full_size_invariants():
         assert st["nan_resets"] == 0 and st["listed_target_substeps"] > 0.5 * n * 15
     finally:
         sim.OnDestroy()
+
+
+def test_global_slot_lists_still_match(oracle):
+    """SPH_FLAG_GLOBAL_LISTS (the list format and kernel of rounds 1-2, kept as a diagnostic and for the targets of over-full
+    tiles): bit-identical to the oracle with the reference's arithmetic, bit-identical to the tile lists in tolerance mode."""
+    n, R, frames = 262144, 47, 4
+    pos0, vel0 = presets.dam_break(n, 0.8, 9)
+    vel0[:, :3] = np.random.default_rng(8).normal(0, 0.4, (n, 3)).astype(np.float32)
+    dt = presets.bench_dt_frame(R)
+    ora = oracle.OracleSimulation(oracle.derive(n, R, 0.8, **SCENE))
+    ora.upload(pos0, vel0)
+    sim = engine(n, R, tile_lists=False, lists="always").Start(pos0, vel0)
+    try:
+        for _ in range(frames):
+            ora.Update(dt)
+            sim.Update(dt)
+        for a, b, what in zip(sim.download(), ora.download(), ("pos", "vel", "rho")):
+            assert_parity(a, b, f"lists of global slots, frame {frames}: {what}")
+        assert sim.stats()["listed_target_substeps"] > n
+    finally:
+        sim.OnDestroy()
+    outs = []
+    for tile in (True, False):
+        sim = engine(n, R, exact_order=False, tile_lists=tile, lists="always").Start(pos0, vel0)
+        sim.step_n(dt, frames)
+        outs.append(sim.download())
+        sim.OnDestroy()
+    for a, b in zip(*outs):
+        assert np.array_equal(a, b, equal_nan=True)
