@@ -1,7 +1,7 @@
 // Device self-test of the arithmetic short cuts the pair kernels take (sph_fastdiv.hpp): shared-reciprocal quotients and the
 // unscaled square root are compared, bit for bit, with the compiler's IEEE `/` and sqrtf on pseudo-random operands that
 // cover the whole window in which the kernels use them (and its edges).
-#include "sph_fastdiv.hpp"
+#include "sph_sweep_common.hpp"
 
 namespace sph {
 
@@ -37,6 +37,9 @@ __global__ void __launch_bounds__(256) k_selftest_arithmetic(uint64_t n, uint64_
         if (__float_as_uint(q) != __float_as_uint(q_ref)) bad_div++;
         const float q2 = div_shared(a, recip_twice(rb)), q2_ref = a / (2.0f * b);
         if (__float_as_uint(q2) != __float_as_uint(q2_ref)) bad_div2++;
+        // without v_div_fixup (pair_finish_folded): the same bits except for the sign of a zero quotient
+        const float qn = div_shared_nofix(a, rb);
+        if (__float_as_uint(qn) != __float_as_uint(q_ref) && !(qn == 0.0f && q_ref == 0.0f)) bad_div++;
         // the window test itself: in-window numerators must pass it, 0 < |t| < 2^-90 must fail it
         if (mag_key(a) < kMagKeyMin) bad_key++;
         const float t = rand_float(r2, 1u, 127u - 91u, true);
