@@ -103,31 +103,37 @@ def cpu_baseline(n, R, fill, pos0, vel0, dt_frame):
     return base, out
 
 
-def committed_csv(suffix, kernel_substr):
-    """Row of the newest committed profiles/*<suffix> for the kernel (rocprofv3 --pmc runs of this command at 16 777 216)."""
+def committed_csv(suffix, kernel_substr, tolerance=False):
+    """Row of the newest committed profiles/*<suffix> for the kernel (rocprofv3 --pmc runs of this command at 16 777 216).
+    The list kernels are templates whose last argument says which arithmetic they were compiled for (true: tolerance mode)."""
     import csv
     import glob
+    import re
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*" + suffix)), reverse=True):   # newest file that has the kernel
         for row in csv.DictReader(open(f)):
             name = row["kernel"]
-            if kernel_substr + "<" in name or kernel_substr + "(" in name:  # (k_velpos_list, not k_velpos_list_changers)
+            if not (kernel_substr + "<" in name or kernel_substr + "(" in name):  # (k_velpos_list, not k_velpos_list_changers)
+                continue
+            m = re.search(re.escape(kernel_substr) + r"<([^>]*)>", name)
+            fast = bool(m) and m.group(1).split(",")[-1].strip() == "true"
+            if fast == tolerance:
                 return row, os.path.relpath(f, ROOT) + " (16 777 216 particles)"
     return None, None
 
 
-def pmc_traffic(kernel_substr):
+def pmc_traffic(kernel_substr, tolerance=False):
     """HBM bytes per launch of the dominant kernel (FETCH_SIZE and WRITE_SIZE in separate passes, KiB).  FETCH_SIZE is
     doubled as MI355X_MICROARCH.md prescribes for wide streaming reads (calibrated on k_upload_split in
     profiles/README.md), so this is an upper bound for the 4-byte-per-lane part of the kernel's reads."""
-    row, src = committed_csv("_hbm_traffic_pmc.csv", kernel_substr)
+    row, src = committed_csv("_hbm_traffic_pmc.csv", kernel_substr, tolerance)
     if row is None:
         return None, None
     return (2.0 * float(row["avg_FETCH_SIZE_raw"]) + float(row["avg_WRITE_SIZE_raw"])) * 1024.0, src
 
 
-def pmc_valu(kernel_substr):
+def pmc_valu(kernel_substr, tolerance=False):
     """Executed wave-level vector instructions per launch of the dominant kernel (SQ_INSTS_VALU, per-launch median)."""
-    row, src = committed_csv("_sq_pmc.csv", kernel_substr)
+    row, src = committed_csv("_sq_pmc.csv", kernel_substr, tolerance)
     if row is None:
         return None, None, None
     return float(row["SQ_INSTS_VALU"]), float(row.get("SQ_INSTS_VALU_TRANS_F32", 0) or 0), src
@@ -298,8 +304,8 @@ def main():
     bytes_substep = BYTES_PER_SUBSTEP if a.precision == 0 else 40     # (6 + 12 + 4) R + (6 + 12) W with fp16 positions
     bytes_step = (32 + 52 * 5) if a.precision == 0 else (20 + 40 * 5)
     achieved = bytes_substep * n / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
-    traffic, traffic_src = pmc_traffic(kernel) if n == 16777216 else (None, None)
-    insts, trans, insts_src = pmc_valu(kernel) if n == 16777216 else (None, None, None)
+    traffic, traffic_src = pmc_traffic(kernel, a.mode == "tolerance") if n == 16777216 else (None, None)
+    insts, trans, insts_src = pmc_valu(kernel, a.mode == "tolerance") if n == 16777216 else (None, None, None)
     # transcendental instructions (v_rcp, v_sqrt) hold the issue port four times as long as the rest
     issue_frac = ((insts + 3.0 * trans) / (kernel_ms * 1e-3) / VALU_ISSUE_PEAK) if insts and kernel_ms > 0 else None
     hbm_frac = achieved / HBM_PEAK_GBS

@@ -105,7 +105,6 @@ struct SphContext {
     uint32_t capacity = 0;            // particles the device arrays can hold
     int z_lo = 0, z_hi = 0, halo_w = 2, has_left = 0, has_right = 0;
     SlabRank *rank = nullptr;         // exchange buffers, counts, snapshot (allocated by sph_slab_configure)
-    VelposFork fork{};                   // second stream of a VelPos sub-step (launch_velpos), created with the context
     hipStream_t comm_stream = nullptr;   // the halo refresh of a two-pass sub-step travels here while `stream` computes
     SlabGroup *group = nullptr;       // the group that steps this slab (owned by the group context, or by this context when it
                                       // is the only local member: one process per GPU)

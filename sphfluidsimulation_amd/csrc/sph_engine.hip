@@ -288,10 +288,10 @@ static void velpos_issue(SphContext *c, uint32_t pass_mode)
         pe.kind = 3;
         pe.a = get_event(c);
         pe.b = get_event(c);
-        launch_velpos(d, c->stream, pe.a, pe.b, &c->fork);
+        launch_velpos(d, c->stream, pe.a, pe.b);
         c->pending.push_back(pe);
     } else {
-        launch_velpos(d, c->stream, nullptr, nullptr, &c->fork);
+        launch_velpos(d, c->stream);
     }
 }
 
@@ -437,12 +437,6 @@ static int create_common(const SphParams *params, uint32_t capacity, bool slab, 
         return bail(SPH_E_HIP);
     }
     c->own_stream = true;
-    if (hipStreamCreateWithFlags(&c->fork.side, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreateWithFlags(&c->fork.forked, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->fork.joined, hipEventDisableTiming) != hipSuccess) {
-        fail(c, SPH_E_HIP, "hipStreamCreate / hipEventCreate failed");
-        return bail(SPH_E_HIP);
-    }
 
     Dev &d = c->dev;
     const size_t n = c->capacity;
@@ -552,9 +546,6 @@ int sph_destroy(SphContext *c)
     if (c->ext_sem) (void)hipDestroyExternalSemaphore(c->ext_sem);
     if (c->owns_group && c->group) slab_group_destroy(c->group);
     slab_rank_destroy(c);
-    if (c->fork.side) (void)hipStreamDestroy(c->fork.side);
-    if (c->fork.forked) (void)hipEventDestroy(c->fork.forked);
-    if (c->fork.joined) (void)hipEventDestroy(c->fork.joined);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return SPH_OK;

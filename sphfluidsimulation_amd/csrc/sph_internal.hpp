@@ -303,14 +303,7 @@ void launch_clear(const Dev &d, uint32_t counter_mask, uint32_t stat_mask, hipSt
 void launch_grid_build(const Dev &d, hipStream_t s);  // keys, histogram, scan, scatter, id-sort, reorder: cur -> nxt
 void launch_density(const Dev &d, hipStream_t s);     // sph_kernels_brick.hip (tiled) + queue
 // cur -> nxt; the optional events bracket k_velpos_list (recorded only in a sub-step that uses neighbour lists)
-// a second stream (and the two events that fork it off and join it back) for the kernels of a VelPos sub-step that can run
-// beside its list kernel; nullptr: everything in stream order
-struct VelposFork {
-    hipStream_t side;
-    hipEvent_t forked, joined;
-};
-void launch_velpos(const Dev &d, hipStream_t s, hipEvent_t list_begin = nullptr, hipEvent_t list_end = nullptr,
-                   const VelposFork *fork = nullptr);
+void launch_velpos(const Dev &d, hipStream_t s, hipEvent_t list_begin = nullptr, hipEvent_t list_end = nullptr);
 void launch_list_prepare(const Dev &d, hipStream_t s);  // sph_kernels_list.hip: which bricks may use their lists
 void launch_frame_report(const Dev &d, unsigned long long *report, bool lists_in_use, hipStream_t s);   // sph_kernels_list.hip
 void launch_velpos_tile_lists(const Dev &d, hipStream_t s, hipEvent_t list_begin = nullptr, hipEvent_t list_end = nullptr);  // sph_kernels_brick_density.hip
