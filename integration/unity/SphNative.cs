@@ -31,8 +31,8 @@ public static class SphNative
         public uint substeps;           // 5,                     :101
         public float dt_divisor;        // 25,                    :102
         public float gravity_x, gravity_y, gravity_z;  // VelPos.compute:7
-        public uint precision;
-        public uint exact_order;
+        public uint precision;          // 0 fp32 positions; 1 fp16 position records (within 1e-4)
+        public uint exact_order;        // 1 the reference's arithmetic bit for bit; 0 tolerance mode (hardware rcp / sqrt, within 1e-4, ~25 % faster)
         public int device_id;
         public uint flags;
         // ABI version 2: 2..8 = split the particles into that many z-slabs, slab i on HIP device device_id<i> (RCCL halo
