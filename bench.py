@@ -159,6 +159,56 @@ def spawn_ranks(a):
     sys.exit(max(rcs) if all(rc >= 0 for rc in rcs) else 1)
 
 
+def supervise(rank, world):
+    """N > 1: the process the launcher started never touches a GPU.  It runs the measurement in a child process and keeps
+    watch: the halo transport over RCCL has never run on more than one GPU (the development box has one), and a collective
+    that hangs cannot be recovered from inside the process that hangs.  If any rank's child fails or exceeds its time limit,
+    EVERY rank starts a second child with the library's host transport (halo messages staged through the host, moved by
+    gloo) -- slower, but a number; the line says which transport produced it (config.decomposition)."""
+    import socket
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)      # control plane of the supervisors (CPU only)
+    forced = os.environ.get("SPH_DIST_TRANSPORT")
+    attempts = [(forced, 1200)] if forced else [("auto", int(os.environ.get("SPH_BENCH_RCCL_LIMIT_S", "420"))), ("host", 1200)]
+    rc, out = 1, ""
+    for transport, limit in attempts:
+        port = [0]
+        if rank == 0:                                                   # a fresh rendezvous port for the workers
+            sk = socket.socket()
+            sk.bind(("127.0.0.1", 0))
+            port[0] = sk.getsockname()[1]
+            sk.close()
+        dist.broadcast_object_list(port, src=0)
+        # (the workers rendezvous among themselves on their own port: the launcher's agent store -- TORCHELASTIC_USE_AGENT_STORE
+        # -- only listens on the port it gave the supervisors)
+        env = {k: v for k, v in os.environ.items() if not k.startswith("TORCHELASTIC_")}
+        env.update(SPH_BENCH_WORKER="1", SPH_DIST_TRANSPORT=transport, MASTER_PORT=str(port[0]))
+        child = subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                 stdout=subprocess.PIPE if rank == 0 else subprocess.DEVNULL, text=True)
+        try:
+            out, _ = child.communicate(timeout=limit)
+            rc = child.returncode
+        except subprocess.TimeoutExpired:
+            child.kill()                                                # (this child, by its handle)
+            out, _ = child.communicate()
+            rc = -9
+            sys.stderr.write(f"bench.py: rank {rank}: the worker with transport '{transport}' exceeded {limit} s and was stopped\n")
+        ok = rc == 0 and (rank != 0 or '"metric"' in (out or ""))
+        flag = torch.tensor([1 if ok else 0])
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 1:
+            if rank == 0:
+                sys.stdout.write(out)
+                sys.stdout.flush()
+            dist.destroy_process_group()
+            sys.exit(0)
+        if rank == 0:
+            sys.stderr.write(f"bench.py: the run with transport '{transport}' failed on some rank (rank 0: rc {rc})\n")
+    dist.destroy_process_group()
+    sys.exit(rc if rc > 0 else 1)
+
+
 def main():
     a = parse()
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -168,6 +218,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if a.gpus != world:
         sys.exit(f"bench.py --gpus {a.gpus} inside a torch.distributed.run world of {world} ranks")
+    if world > 1 and os.environ.get("SPH_BENCH_WORKER") != "1":
+        supervise(rank, world)
 
     from sphfluidsimulation_amd import presets
 

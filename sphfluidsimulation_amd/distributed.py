@@ -343,7 +343,8 @@ def bench_main(a, n, R, fill, dt_frame, rank, world, local_rank):
     os.environ.setdefault("MASTER_PORT", "29577")
     os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")   # one node: RCCL's bootstrap needs no external interface
     if not dist.is_initialized() and world > 1:
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+        import datetime
+        dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=300))
     pos0, vel0 = presets.dam_break(n, fill, a.seed)
     sim = SlabSimulation(rank, world, n, R, fill, 0.01, 1.5, 150.0, 5000.0, 10.0, device_id=local_rank,
                          halo_w=2, profile=True, transport=transport, precision=getattr(a, "precision", 0),

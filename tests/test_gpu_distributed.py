@@ -257,3 +257,23 @@ def test_bench_two_ranks_as_the_driver_launches_it():
     out = json.loads(line)
     assert out["n_gpus"] == 2 and out["value"] > 0 and out["halo_violations"] == 0
     assert "host" in out["config"]["decomposition"]
+
+
+def test_bench_falls_back_to_the_host_transport_when_a_worker_hangs():
+    """The launcher's processes only supervise (bench.py::supervise): when a rank's worker does not finish within its limit --
+    here one second, standing in for a collective that hangs on hardware this box does not have -- every rank stops its worker
+    and starts another one with the library's host transport, and rank 0 still prints its line.  Launched as the driver
+    launches N > 1: python -m torch.distributed.run."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "SPH_DIST_TRANSPORT")}
+    env.update(SPH_DIST_SINGLE_DEVICE="1", SPH_BENCH_RCCL_LIMIT_S="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--particles", "262144",
+                        "--steps", "3", "--warmup", "2"], capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert "exceeded 1 s and was stopped" in r.stderr
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["n_gpus"] == 2 and out["value"] > 0 and "host" in out["config"]["decomposition"]
