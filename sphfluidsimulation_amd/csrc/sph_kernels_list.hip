@@ -200,7 +200,7 @@ __device__ __forceinline__ void walk_list_and_integrate(const Dev &d, uint32_t s
             a1 = b1;
         }
     }
-    if (live) integrate_store<PREC>(d, s, pix, piy, piz, vix, viy, viz, viw, rho_i, f);  // :100-157
+    if (live) integrate_store<PREC, FAST>(d, s, pix, piy, piz, vix, viy, viz, viw, rho_i, f);  // :100-157
 }
 
 // VelPos.compute:46-158 for the targets of CALM bricks, one lane per slot: pair sums from the list recorded by the
@@ -258,8 +258,8 @@ __global__ void __launch_bounds__(kListBlock, SPH_LIST_MINWAVES) k_velpos_list(D
     enqueue_block(d, hand_over, s, s_queue, d.queue2, kCntQueue2);
     if (!live) n = 0;
     walk_list_and_integrate<PREC, FAST>(d, s, n, t.mask, live, t.px, t.py, t.pz);
-    stat_add(d, kStatListed, live ? 1ull : 0ull);
-    stat_add(d, kStatListEntries, (unsigned long long)n);
+    stat_count(d, kStatListed, live);
+    stat_add_u32(d, kStatListEntries, n);
 }
 
 // The targets of k_velpos_list that changed cell since the lists were recorded: a bin that ENTERED their stencil might

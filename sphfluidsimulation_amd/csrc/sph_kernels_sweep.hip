@@ -141,7 +141,10 @@ __device__ __forceinline__ void velpos_target(const Dev &d, uint32_t s, bool liv
             }
         }
     }
-    if (live) integrate_store(d, s, pix, piy, piz, vix, viy, viz, viw, rho_i, f);
+    if (live) {
+        if (d.fast) integrate_store<-1, true>(d, s, pix, piy, piz, vix, viy, viz, viw, rho_i, f);   // tolerance mode (launch-uniform)
+        else integrate_store(d, s, pix, piy, piz, vix, viy, viz, viw, rho_i, f);
+    }
 }
 
 // ---- kernels over every slot (used when the brick path is disabled) ----------------------------------

@@ -239,7 +239,8 @@ __device__ __forceinline__ void pair_force(const Dev &d, uint32_t j, float pix, 
 }
 
 // VelPos.compute:100-157: scaling, wall force, NaN guard, integrate, clamp, store.  Returns the new position.
-template <int PREC = -1>
+// FAST (tolerance mode, launch-uniform): the five divisions by rho_i and m become two reciprocals.
+template <int PREC = -1, bool FAST = false>
 __device__ __forceinline__ Pos3 integrate_store(const Dev &d, uint32_t s, float pix, float piy, float piz,
                                                 float vix, float viy, float viz, float viw, float rho_i,
                                                 Force f)
@@ -248,9 +249,9 @@ __device__ __forceinline__ Pos3 integrate_store(const Dev &d, uint32_t s, float 
     const float h = d.h, m = d.mass;
     const float dt = d.dt_ptr ? *d.dt_ptr : d.dt;
     if (rho_i > epsilon) {                                                       // :101
-        const float sp = m * m / rho_i;                                          // :103
+        const float sp = FAST ? (m * m) * __builtin_amdgcn_rcpf(rho_i) : m * m / rho_i;                         // :103
         f.px *= sp; f.py *= sp; f.pz *= sp;
-        const float sv = d.viscosity * m * m / rho_i;                            // :104
+        const float sv = FAST ? (d.viscosity * m * m) * __builtin_amdgcn_rcpf(rho_i) : d.viscosity * m * m / rho_i;   // :104
         f.vx *= sv; f.vy *= sv; f.vz *= sv;
     }
     float fwx = 0.0f, fwy = 0.0f, fwz = 0.0f;                                    // :107
@@ -272,9 +273,10 @@ __device__ __forceinline__ Pos3 integrate_store(const Dev &d, uint32_t s, float 
         fwz = wrz * d.stiffness - dd;
         fwx *= m; fwy *= m; fwz *= m;                                            // :136
     }
-    const float ax = d.gx + ((f.px + f.vx) + fwx) / m;                           // :139
-    const float ay = d.gy + ((f.py + f.vy) + fwy) / m;
-    const float az = d.gz + ((f.pz + f.vz) + fwz) / m;
+    const float rm = FAST ? __builtin_amdgcn_rcpf(m) : 0.0f;
+    const float ax = d.gx + (FAST ? ((f.px + f.vx) + fwx) * rm : ((f.px + f.vx) + fwx) / m);   // :139
+    const float ay = d.gy + (FAST ? ((f.py + f.vy) + fwy) * rm : ((f.py + f.vy) + fwy) / m);
+    const float az = d.gz + (FAST ? ((f.pz + f.vz) + fwz) * rm : ((f.pz + f.vz) + fwz) / m);
     float vox, voy, voz, vow;
     if (ax != ax || ay != ay || az != az) {                                      // :143
         vox = 0.0f; voy = 0.0f; voz = 0.0f; vow = 0.003f;                        // :145-146
@@ -318,6 +320,23 @@ __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
 #pragma unroll
     for (int o = kWave / 2; o > 0; o >>= 1) v += __shfl_down(v, o, kWave);
     return v;
+}
+
+// the same for per-lane values whose wave total fits 32 bits (half the instructions: the kernels that call it per wave are
+// VALU-bound)
+__device__ __forceinline__ void stat_add_u32(const Dev &d, int stat, uint32_t v)
+{
+#pragma unroll
+    for (int o = kWave / 2; o > 0; o >>= 1) v += __shfl_down(v, o, kWave);
+    if ((threadIdx.x & (kWave - 1)) == 0 && v)
+        atomicAdd(&d.stripes[((size_t)stat * kStatStripes + (blockIdx.x % kStatStripes)) * kStatPad], (unsigned long long)v);
+}
+// ... and for a per-lane flag: one ballot
+__device__ __forceinline__ void stat_count(const Dev &d, int stat, bool flag)
+{
+    const unsigned long long m = __ballot(flag);
+    if ((threadIdx.x & (kWave - 1)) == 0 && m)
+        atomicAdd(&d.stripes[((size_t)stat * kStatStripes + (blockIdx.x % kStatStripes)) * kStatPad], (unsigned long long)__popcll(m));
 }
 
 // wave total of `v` into the block's stripe of statistic `stat` (every lane of the wave must call it)
