@@ -191,3 +191,32 @@ def test_global_slot_lists_still_match(oracle):
         sim.OnDestroy()
     for a, b in zip(*outs):
         assert np.array_equal(a, b, equal_nan=True)
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("SPH_FUZZ_SEEDS", "10"))))
+def test_random_configurations_tolerance_routes(seed):
+    """Random sizes, grids, fill rates, speeds and scalars in tolerance mode: tile lists, lists of global slots and no lists at
+    all give the same bits (whatever mixture of list, scanning, hand-over and generic kernels each ends up on)."""
+    rng = np.random.default_rng(5000 + seed)
+    n = int(rng.choice([1024, 4096, 16384, 65536]))
+    R = int(rng.integers(4, 40)) if seed % 3 else int(rng.choice([2, 3, 64, 128]))
+    fill = float(rng.choice([0.3, 0.5, 0.8, 1.0]))
+    speed = float(rng.choice([0.0, 0.05, 0.5, 5.0]))
+    scal = dict(viscosity=float(rng.uniform(0.0, 0.1)), restDensity=float(rng.uniform(0.5, 3.0)),
+                gasConstant=float(rng.uniform(10.0, 500.0)), stiffnessCoefficient=float(rng.uniform(1000.0, 10000.0)),
+                dampingCoefficient=float(rng.uniform(1.0, 50.0)))
+    pos0, vel0 = presets.dam_break(n, fill, seed=seed, jitter=float(rng.choice([0.0, 0.3, 1.0])))
+    vel0[:, :3] = rng.standard_normal((n, 3)).astype(np.float32) * np.float32(speed)
+    dt = float(rng.uniform(0.05, 1.0)) / (R - 1 if R > 1 else 1) * 0.7666667
+    frames = int(rng.integers(3, 8))
+    outs = []
+    for kw in (dict(lists="always"), dict(lists="always", tile_lists=False), dict(lists=False)):
+        sim = engine(n, R, exact_order=False, **dict(kw, **scal))
+        sim.damFillRate = fill
+        sim.Start(pos0, vel0)
+        sim.step_n(dt, frames)
+        outs.append(sim.download())
+        sim.OnDestroy()
+    for k, o in enumerate(outs[1:]):
+        for a, b, what in zip(outs[0], o, ("pos", "vel", "rho")):
+            assert np.array_equal(a, b, equal_nan=True), f"route {k + 1}: {what}: n={n} R={R} fill={fill} speed={speed} frames={frames}"
