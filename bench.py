@@ -414,7 +414,7 @@ def main():
             out["tolerance_mode"]["parity_frames"] = CPU_FRAMES
             out["tolerance_mode"]["parity_vs_oracle"] = {
                 "pos_max_abs": float(np.abs(tol_state[0][:, :3] - po[:, :3]).max()), "vel_max_rel": float(ev.max()),
-                "vel_p99.99_rel": float(np.percentile(ev, 99.99)),
+                "vel_p99.99_rel": float(np.percentile(ev, 99.99)), "particles_beyond_1e-4": int((ev > 1e-4).sum()),
                 "rho_max_rel": float((np.abs(tol_state[2].astype(np.float64) - ro) / np.maximum(np.abs(ro), 1e-6)).max())}
     sim.OnDestroy()
     print(json.dumps(out), flush=True)
