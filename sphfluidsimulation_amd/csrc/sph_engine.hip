@@ -1024,6 +1024,10 @@ int sph_set_params(SphContext *c, const SphParams *p)
     if (p->num_devices != c->params.num_devices || p->halo_planes != c->params.halo_planes)
         return fail(c, SPH_E_INVALID_ARG, "num_devices / halo_planes are fixed at sph_create");
     if (c->is_group) return group_set_params(c, p);
+    // lists recorded by the density pass of the frame in flight (staged calls) were recorded FOR a format, a kernel set and a
+    // skin: a change of any of them retires them (the rest of the frame scans; the next density pass records again)
+    constexpr uint32_t kListFlags = SPH_FLAG_GLOBAL_LISTS | SPH_FLAG_NO_TILING | SPH_FLAG_NO_LISTS;
+    if (((p->flags ^ c->params.flags) & kListFlags) != 0u || p->list_skin != c->params.list_skin) c->nl_recorded = false;
     c->params = *p;
     c->profile = (p->flags & SPH_FLAG_PROFILE) != 0;
     // per-pass events cannot be recorded inside a captured frame: a context that profiles issues its launches directly
