@@ -94,7 +94,7 @@ struct Dev {
 };
 
 enum : uint32_t { kNlOff = 0, kNlBuild = 1, kNlUse = 2 };
-enum : uint8_t { kBrickUnlisted = 1, kBrickActive = 2 };
+enum : uint8_t { kBrickUnlisted = 1, kBrickActive = 2, kBrickEmpty = 4 };   // (Empty: no slot in the rows of the brick's bins, set per sub-step)
 #ifndef SPH_CHUNK_SLOTS
 #define SPH_CHUNK_SLOTS 64
 #endif

@@ -87,10 +87,8 @@ __global__ void __launch_bounds__(kBlock) k_brick_activity(Dev d, int nbx, int n
     static_assert(kRY * kRZ <= kWave, "one lane per row");
     float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
     bool own_nonempty = false;
-    if (d.nl_still) {                              // first sub-step: every displacement is zero, no chunk boxes yet
-        lo[0] = lo[1] = lo[2] = hi[0] = hi[1] = hi[2] = 0.0f;
-        own_nonempty = true;
-    } else if (lane < kRY * kRZ) {
+    if (d.nl_still) lo[0] = lo[1] = lo[2] = hi[0] = hi[1] = hi[2] = 0.0f;   // first sub-step: every displacement is zero, no chunk boxes yet
+    if (lane < kRY * kRZ) {
         const int cy = y0 - 1 + lane % kRY, cz = z0 - 1 + lane / kRY;
         if (cy >= 0 && cz >= 0 && cy < R && cz < R) {
             const int xa = x0 - 1 > 0 ? x0 - 1 : 0, xb = x0 + kNlBX < R - 1 ? x0 + kNlBX : R - 1;   // bins xa..xb
@@ -98,6 +96,7 @@ __global__ void __launch_bounds__(kBlock) k_brick_activity(Dev d, int nbx, int n
             const uint32_t s0 = d.cell_start[rk + (uint32_t)xa], s1 = d.cell_start[rk + (uint32_t)xb + 1u];
             if (s1 > s0) {
                 own_nonempty = cy >= y0 && cy < y0 + kNlBY && cz >= z0 && cz < z0 + kNlBZ;   // (roughly: the row)
+                if (!d.nl_still)
                 for (uint32_t c = s0 / kChunkSlots; c <= (s1 - 1) / kChunkSlots; c++)
 #pragma unroll
                     for (int a = 0; a < 3; a++) {
@@ -126,7 +125,7 @@ __global__ void __launch_bounds__(kBlock) k_brick_activity(Dev d, int nbx, int n
         const float rho = sqrtf(r2) * 1.00001f;
         const uint8_t st = d.brick_state[b] & kBrickUnlisted;
         const bool active = blocked || st != 0 || !(rho <= d.skin_ok);   // NaN-safe
-        d.brick_state[b] = st | (active ? kBrickActive : 0);
+        d.brick_state[b] = st | (active ? kBrickActive : 0) | (nonempty ? 0 : kBrickEmpty);   // (Empty: k_velpos_tile need not look)
         if (active && nonempty && !blocked) atomicAdd(&d.counters[kCntActiveBricks], 1ull);
         if (active) my_pos = atomicAdd(&s_act[0], 1u);
     }
