@@ -13,6 +13,9 @@
 #define SPH_RECORD_MINWAVES 6
 #endif
 #define SPH_BRICK_EMIT_DENSITY 1
+#ifndef SPH_SCAN_UNROLL
+#define SPH_SCAN_UNROLL 2     /* slots per trip of the density scan (2 / 3 / 4: 2.36 / 2.36 / 2.41 ms with RECORD: the runs are short, ~11 slots) */
+#endif
 #ifndef SPH_D_BX
 #define SPH_D_BX 4
 #endif
