@@ -135,7 +135,8 @@ typedef struct SphStats {
     uint64_t listed_target_substeps;  /* target sub-steps whose pair sums came from the list of sub-step 1 */
     uint64_t scanned_brick_substeps;  /* non-empty 4x4x4 bricks that had to re-scan in a sub-step 2..S     */
     uint64_t list_entries;            /* list entries those target sub-steps walked                        */
-    double ms_velpos_list;            /* GPU time of k_velpos_list alone (part of ms_velpos), SPH_FLAG_PROFILE */
+    double ms_velpos_list;            /* GPU time of the list kernel alone -- k_velpos_tile, or k_velpos_list under
+                                         SPH_FLAG_GLOBAL_LISTS -- (part of ms_velpos), SPH_FLAG_PROFILE                */
     uint64_t launches_velpos_list;
     uint64_t graph_replays;           /* sph_step frames replayed from a captured HIP graph since create         */
     uint64_t frames_without_lists;    /* sph_step frames the list policy ran without recording (lists would not pay) */

@@ -126,3 +126,15 @@ def test_product_does_not_use_the_oracle():
             assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), f
             assert "libsph_oracle" not in text and "sph_oracle.py" not in text, f
             assert not re.search(r"#include\s+[\"<].*oracle", text), f
+
+
+def test_flag_constants_match_the_header():
+    """Every SPH_FLAG_* of include/sph_hip.h has the same value in the Python mirror (the C# shim and the tests pass them)."""
+    import re
+    from sphfluidsimulation_amd import _native as N
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "include", "sph_hip.h")).read()
+    flags = dict(re.findall(r"#define (SPH_FLAG_[A-Z_]+) (\d+)u", text))
+    assert len(flags) >= 9 and len(set(flags.values())) == len(flags)      # distinct bits
+    for name, value in flags.items():
+        assert getattr(N, name) == int(value), name
