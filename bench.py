@@ -55,6 +55,7 @@ def parse():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--mode", choices=["exact", "tolerance"], default="exact",
                     help="exact: bit-identical to the CPU oracle (SphParams.exact_order = 1); tolerance: hardware reciprocal / sqrt, parity bar 1e-4")
+    ap.add_argument("--list-skin", type=float, default=0.0, help="diagnostic: neighbour-list skin / h (0 = the default 0.04)")
     ap.add_argument("--global-lists", action="store_true", help="diagnostic: lists of global slots gathered through L1 by k_velpos_list (SPH_FLAG_GLOBAL_LISTS)")
     ap.add_argument("--precision", type=int, default=0, help="1: positions stored as fp16 cell offsets (BASELINE config 5), arithmetic fp32")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -241,7 +242,7 @@ def main():
     sim = SphFluidSimulation(particleNumber=n, bucketResolution=R, damFillRate=fill, viscosity=0.01,
                              restDensity=1.5, gasConstant=150.0, stiffnessCoefficient=5000.0,
                              dampingCoefficient=10.0, device_id=0, profile=True, precision=a.precision,
-                             exact_order=a.mode == "exact", tile_lists=not a.global_lists).Start(pos0, vel0)
+                             exact_order=a.mode == "exact", tile_lists=not a.global_lists, list_skin=a.list_skin).Start(pos0, vel0)
 
     # GPU result after CPU_FRAMES frames, checked against the CPU baseline run below; then start over for the timing
     warm = a.warmup
