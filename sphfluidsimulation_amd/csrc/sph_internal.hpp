@@ -10,6 +10,16 @@ namespace sph {
 constexpr uint32_t kMaxPerVoxel = 32;  // MaxParticlesPerVoxel, SphFluidSimulation.cs:9
 constexpr int kWave = 64;              // CDNA4 wavefront
 
+// A workgroup barrier that orders LDS only.  __syncthreads() fences every address space, which on gfx9 means
+// s_waitcnt vmcnt(0): every global load, store and atomic in flight is waited for.  Use where the threads only hand each
+// other LDS data and something global should stay in the air across the barrier.
+__device__ __forceinline__ void lds_barrier()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 // One set of cell-sorted SoA particle arrays (ping-pong partner of another set).
 struct Soa {
     float *x, *y, *z;     // position, SoA: what the neighbour scans stream (pos.w is derived, see k_download); nullptr when
