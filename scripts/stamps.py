@@ -16,7 +16,11 @@ L = N.lib(); L.sph_debug_read_order.argtypes = [C.c_void_p, C.c_void_p, C.c_size
 assert L.sph_debug_read_order(sim._ctx, buf.ctypes.data_as(C.c_void_p), buf.nbytes) == 0
 b = buf[buf[:, 4] > 0].astype(np.int64)
 print("bricks with targets:", len(b), "of", nb)
-for name, a, c in (("setup", 0, 1), ("scan", 1, 2), ("phase2", 2, 3), ("integrate+store", 3, 4), ("total", 0, 4)):
+phases = (("setup", 0, 1), ("scan", 1, 2), ("phase2", 2, 3), ("integrate+store", 3, 4), ("total", 0, 4))
+if b[:, 5].max() > 0:      # k_velpos_tile (SPH_STAMPS=2): start -> rows known -> cell table + offsets -> tile staged -> target ready -> walked -> stored
+    phases = (("rows (+cell loads)", 0, 5), ("cell table + offsets", 5, 6), ("tile staged", 6, 1), ("entry rows + target", 1, 2), ("walk", 2, 3),
+              ("integrate + store", 3, 4), ("total", 0, 4))
+for name, a, c in phases:
     dt = (b[:, c] - b[:, a])
     print(f"{name:16s} mean {dt.mean():9.0f} cycles  median {np.median(dt):9.0f}  p90 {np.percentile(dt, 90):9.0f}  ({dt.mean()/100:.1f} us at 100 MHz ticks?)")
 span = b[:, 4].max() - b[:, 0].min()
