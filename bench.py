@@ -167,6 +167,10 @@ def supervise(rank, world):
     EVERY rank starts a second child with the library's host transport (halo messages staged through the host, moved by
     gloo) -- slower, but a number; the line says which transport produced it (config.decomposition)."""
     import socket
+    # rank 0 owes the launcher ONE JSON line on stdout: gloo and RCCL print banners there ("[Gloo] Rank 0 is connected ...",
+    # "RCCL version ..."), from this process and from the worker -- everything but the line goes to stderr
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     import torch
     import torch.distributed as dist
     dist.init_process_group("gloo", rank=rank, world_size=world)      # control plane of the supervisors (CPU only)
@@ -200,8 +204,9 @@ def supervise(rank, world):
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         if int(flag.item()) == 1:
             if rank == 0:
-                sys.stdout.write(out)
-                sys.stdout.flush()
+                lines = [l for l in (out or "").splitlines() if l.startswith("{") and '"metric"' in l]
+                sys.stderr.write("".join(l + "\n" for l in (out or "").splitlines() if l not in lines[-1:]))
+                os.write(real_stdout, (lines[-1] + "\n").encode())
             dist.destroy_process_group()
             sys.exit(0)
         if rank == 0:
