@@ -254,6 +254,7 @@ def test_bench_two_ranks_as_the_driver_launches_it():
                         "--warmup", "2"], capture_output=True, text=True, env=env, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    assert [l for l in r.stdout.splitlines() if l.strip()] == [line], r.stdout[:2000]   # ONE line on stdout: gloo / RCCL banners go to stderr
     out = json.loads(line)
     assert out["n_gpus"] == 2 and out["value"] > 0 and out["halo_violations"] == 0
     assert "host" in out["config"]["decomposition"]
