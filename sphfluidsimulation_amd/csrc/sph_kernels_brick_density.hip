@@ -7,7 +7,7 @@
 #define SPH_DENSITY_MINWAVES 7
 #endif
 #ifndef SPH_RECORD_CAP
-#define SPH_RECORD_CAP 1024
+#define SPH_RECORD_CAP 928    /* tile of the recording pass and of k_velpos_tile (32 B per particle there: five workgroups per CU) */
 #endif
 #ifndef SPH_RECORD_MINWAVES
 #define SPH_RECORD_MINWAVES 6

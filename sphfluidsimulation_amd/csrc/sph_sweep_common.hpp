@@ -146,9 +146,11 @@ __device__ __forceinline__ float div_shared_nofix(float a, const Recip &d)
     const float e1 = __builtin_fmaf(-d.b, q1, a);
     return __builtin_fmaf(e1, d.r, q1);
 }
-__device__ __forceinline__ void pair_finish_folded(const Dev &d, const PairPre &q, Force &f)
+// rr_r: the refined reciprocal of rho_j, recip_refined(q.rho_j).r -- a caller that holds it (k_velpos_tile stages it with the
+// candidate) passes it in, everybody else computes it here.
+__device__ __forceinline__ void pair_finish_folded(const Dev &d, const PairPre &q, Force &f, float rr_r)
 {
-    const Recip ra = recip_refined(q.abs_r), rr = recip_refined(q.rho_j), r2 = recip_twice(rr);
+    const Recip ra = recip_refined(q.abs_r), rr{q.rho_j, rr_r}, r2 = recip_twice(rr);
     const float gpx = div_shared_nofix(q.ngx, ra), gpy = div_shared_nofix(q.ngy, ra), gpz = div_shared_nofix(q.ngz, ra);
     const float cp = div_shared_nofix(q.ncp, r2);
     const float qx = div_shared_nofix(q.nvx, rr), qy = div_shared_nofix(q.nvy, rr), qz = div_shared_nofix(q.nvz, rr);
@@ -162,6 +164,10 @@ __device__ __forceinline__ void pair_finish_folded(const Dev &d, const PairPre &
     f.vx += sel_v ? ux : 0.0f;
     f.vy += sel_v ? uy : 0.0f;
     f.vz += sel_v ? uz : 0.0f;
+}
+__device__ __forceinline__ void pair_finish_folded(const Dev &d, const PairPre &q, Force &f)
+{
+    pair_finish_folded(d, q, f, recip_refined(q.rho_j).r);
 }
 
 // Two candidates (a then b: the reference's order) of a launch that is not "wild".  FOLDED: pair_finish_folded.
@@ -187,13 +193,14 @@ __device__ __forceinline__ void pair_force_two(const Dev &d, const PairPre &a, c
 // relative error of a pair term ~1e-6, the parity bar of this mode is BASELINE.json's 1e-4 (tests/test_gpu_tolerance_mode.py).
 // No "wild" detour: extreme operands give inf / NaN here as in IEEE arithmetic, not necessarily in the same lanes.
 __device__ __forceinline__ void pair_fast(const Dev &d, float rx, float ry, float rz, float rho_j, float vjx, float vjy,
-                                          float vjz, float vix, float viy, float viz, float p_i, Force &f, bool take)
+                                          float vjz, float vix, float viy, float viz, float p_i, Force &f, bool take, float rrho)
 {
+    // rrho = v_rcp_f32(rho_j): passed in by a caller that holds it (k_velpos_tile stages it with the candidate)
     const float epsilon = 1e-6f;                                                 // :5
     const float h = d.h;
     const float r2 = __builtin_fmaf(rz, rz, __builtin_fmaf(ry, ry, rx * rx));
     const float abs_r = __builtin_amdgcn_sqrtf(r2);                              // :35, :42
-    const float rinv = __builtin_amdgcn_rcpf(abs_r), rrho = __builtin_amdgcn_rcpf(rho_j);
+    const float rinv = __builtin_amdgcn_rcpf(abs_r);
     const float diff_r = h - abs_r;                                              // :36
     const bool ok = take && (rho_j > epsilon);                                   // :91
     const bool sel_p = ok && (epsilon < diff_r) && (epsilon < abs_r);            // :37
@@ -209,6 +216,12 @@ __device__ __forceinline__ void pair_fast(const Dev &d, float rx, float ry, floa
     f.vx = __builtin_fmaf(sv, vjx - vix, f.vx);
     f.vy = __builtin_fmaf(sv, vjy - viy, f.vy);
     f.vz = __builtin_fmaf(sv, vjz - viz, f.vz);
+}
+
+__device__ __forceinline__ void pair_fast(const Dev &d, float rx, float ry, float rz, float rho_j, float vjx, float vjy,
+                                          float vjz, float vix, float viy, float viz, float p_i, Force &f, bool take)
+{
+    pair_fast(d, rx, ry, rz, rho_j, vjx, vjy, vjz, vix, viy, viz, p_i, f, take, __builtin_amdgcn_rcpf(rho_j));
 }
 
 // One candidate; `literal` = the launch is wild (wave-uniform).
