@@ -173,6 +173,7 @@ enum Counter : int {
     kCntQueue2,         // length of queue2 (targets k_velpos_list hands to k_velpos_list_changers) for the sub-step in flight
     kCntIrregular,      // last grid build saw a position outside [0,1] (or NaN): bins say nothing about positions
     kCntListTooLong,    // targets of the last recording density pass whose list exceeded nl_cap (their bricks scan)
+    kCntQueueHead,      // next unclaimed entry of `queue`: the queue kernels deal it out in chunks of one block
     kCntCount
 };
 

@@ -20,7 +20,19 @@ namespace sph {
 
 constexpr int kBlock = 256;
 constexpr int kListCap = 64;          // entries per lane; a cell adds at most 32
-constexpr int kQueueGrid = 2048;      // blocks of the queue kernels (grid-stride over the queue)
+// The queue kernels are persistent grids of as many blocks as the device keeps resident (queue_grid below); the blocks
+// claim the queue in chunks of kBlock entries from a device counter (queue_claim).  Targets differ a lot in cost -- a member
+// of a floor cell late in a dam break walks 300+ candidates, a target that merely changed cell ~100 -- so a static deal of
+// the chunks leaves blocks idle: 2048 blocks strided (until round 3; 1280 resident) 5.2 ms, 1280 blocks strided 6.6 ms.
+__device__ __forceinline__ uint32_t queue_claim(const Dev &d, uint32_t *s_q0)
+{
+    __syncthreads();                                   // everybody is done with the previous chunk (and with s_q0)
+    if (threadIdx.x == 0) *s_q0 = (uint32_t)atomicAdd(&d.counters[kCntQueueHead], (unsigned long long)kBlock);
+    __syncthreads();
+    const uint32_t q0 = *s_q0;
+    __syncthreads();                                   // (the word may be part of a buffer the chunk's work reuses)
+    return q0;
+}
 
 // ---- Density.compute:29-60 for target slot s -------------------------------------------------------
 
@@ -44,15 +56,27 @@ __device__ __forceinline__ uint32_t density_target(const Dev &d, uint32_t s)
                 const CellRange cr = cell_range(d, ix + xo, iy + yo, iz + zo);
                 visited += cr.cnt;
                 const uint32_t code = (uint32_t)(((xo + 1) * 3 + (yo + 1)) * 3 + (zo + 1));
-                for (uint32_t k = 0; k < cr.cnt; k++) {
-                    const uint32_t j = cr.start + k;
-                    const Pos3 pj = load_pos(d, d.cur, j);
-                    const float rx = pix - pj.x, ry = piy - pj.y, rz = piz - pj.z;
-                    const float r2 = (rx * rx + ry * ry) + rz * rz;              // Density.compute:24
-                    rho += d.fast ? density_term_r2<true>(d, r2) : density_term_r2<false>(d, r2);
-                    if (RECORD && r2 < d.h2_list) {                              // superset of |r| < h + skin
-                        if (gn < d.nl_cap) nl_row[gn * kWave] = (code << kNlSlotBits) | j;
-                        gn++;
+                // four candidates per trip, their loads issued together (one 16-byte load each where the packed copy exists): a
+                // trip per candidate waited for one memory round trip per candidate
+                constexpr uint32_t kTrip = 4;
+                for (uint32_t k0 = 0; k0 < cr.cnt; k0 += kTrip) {
+                    Pos3 pj[kTrip];
+#pragma unroll
+                    for (uint32_t u = 0; u < kTrip; u++) {
+                        const uint32_t j = cr.start + (k0 + u < cr.cnt ? k0 + u : cr.cnt - 1u);
+                        pj[u] = d.cur.p4 ? load_p4(d, d.cur, j) : load_pos(d, d.cur, j);
+                    }
+#pragma unroll
+                    for (uint32_t u = 0; u < kTrip; u++) {
+                        if (k0 + u >= cr.cnt) break;
+                        const uint32_t j = cr.start + k0 + u;
+                        const float rx = pix - pj[u].x, ry = piy - pj[u].y, rz = piz - pj[u].z;
+                        const float r2 = (rx * rx + ry * ry) + rz * rz;          // Density.compute:24
+                        rho += d.fast ? density_term_r2<true>(d, r2) : density_term_r2<false>(d, r2);
+                        if (RECORD && r2 < d.h2_list) {                          // superset of |r| < h + skin
+                            if (gn < d.nl_cap) nl_row[gn * kWave] = (code << kNlSlotBits) | j;
+                            gn++;
+                        }
                     }
                 }
             }
@@ -171,9 +195,10 @@ __global__ void __launch_bounds__(kBlock) k_velpos_exact(Dev d)
 
 __global__ void __launch_bounds__(kBlock) k_density_queue(Dev d)
 {
+    __shared__ uint32_t s_q0;
     const uint32_t qlen = (uint32_t)d.counters[kCntQueue];
     unsigned long long v = 0;
-    for (uint32_t q0 = blockIdx.x * kBlock; q0 < qlen; q0 += gridDim.x * kBlock) {
+    for (uint32_t q0 = queue_claim(d, &s_q0); q0 < qlen; q0 = queue_claim(d, &s_q0)) {   // block-uniform
         const uint32_t q = q0 + threadIdx.x;
         if (q < qlen && !(d.ghost && d.ghost[d.queue[q]]))
             v += d.nl_mode == kNlBuild ? density_target<true>(d, d.queue[q]) : density_target<false>(d, d.queue[q]);
@@ -183,9 +208,9 @@ __global__ void __launch_bounds__(kBlock) k_density_queue(Dev d)
 
 __global__ void __launch_bounds__(kBlock) k_velpos_queue(Dev d)
 {
-    __shared__ uint32_t lds_list[(kListCap / 2) * kBlock];
+    __shared__ uint32_t lds_list[(kListCap / 2) * kBlock];   // 32 KB: five blocks per CU (one word more would make it four)
     const uint32_t qlen = (uint32_t)d.counters[kCntQueue];
-    for (uint32_t q0 = blockIdx.x * kBlock; q0 < qlen; q0 += gridDim.x * kBlock) {  // block-uniform
+    for (uint32_t q0 = queue_claim(d, lds_list); q0 < qlen; q0 = queue_claim(d, lds_list)) {   // block-uniform
         const uint32_t q = q0 + threadIdx.x;
         const bool live = q < qlen;
         velpos_target(d, d.queue[live ? q : qlen - 1], live, reinterpret_cast<uint16_t *>(lds_list), threadIdx.x);
@@ -193,6 +218,20 @@ __global__ void __launch_bounds__(kBlock) k_velpos_queue(Dev d)
 }
 
 static inline uint32_t cdiv(uint32_t a, uint32_t b) { return a ? (a + b - 1) / b : 1u; }  // never an empty grid
+
+// resident blocks of a queue kernel on the current device (asked once per kernel and device)
+template <typename K>
+static uint32_t queue_grid(K kernel, uint32_t &cached)
+{
+    if (cached == 0u) {
+        int dev = 0, cus = 0, per_cu = 0;
+        (void)hipGetDevice(&dev);
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kBlock, 0) != hipSuccess || per_cu < 1) per_cu = 4;
+        cached = (uint32_t)(cus > 0 ? cus : 256) * (uint32_t)per_cu;
+    }
+    return cached;
+}
 
 void launch_density_all(const Dev &d, hipStream_t s)
 {
@@ -206,14 +245,16 @@ void launch_velpos_all(const Dev &d, hipStream_t s)
 
 void launch_density_queue(const Dev &d, hipStream_t s)
 {
-    const uint32_t g = cdiv(d.count, kBlock);
-    hipLaunchKernelGGL(k_density_queue, dim3(g < (uint32_t)kQueueGrid ? g : kQueueGrid), dim3(kBlock), 0, s, d);
+    static uint32_t resident = 0;
+    const uint32_t g = cdiv(d.count, kBlock), cap = queue_grid(k_density_queue, resident);
+    hipLaunchKernelGGL(k_density_queue, dim3(g < cap ? g : cap), dim3(kBlock), 0, s, d);
 }
 
 void launch_velpos_queue(const Dev &d, hipStream_t s)
 {
-    const uint32_t g = cdiv(d.count, kBlock);
-    hipLaunchKernelGGL(k_velpos_queue, dim3(g < (uint32_t)kQueueGrid ? g : kQueueGrid), dim3(kBlock), 0, s, d);
+    static uint32_t resident = 0;
+    const uint32_t g = cdiv(d.count, kBlock), cap = queue_grid(k_velpos_queue, resident);
+    hipLaunchKernelGGL(k_velpos_queue, dim3(g < cap ? g : cap), dim3(kBlock), 0, s, d);
 }
 
 }  // namespace sph
