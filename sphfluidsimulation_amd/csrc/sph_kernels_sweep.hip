@@ -18,6 +18,9 @@
 
 namespace sph {
 
+#ifndef SPH_QUEUE_TRIP
+#define SPH_QUEUE_TRIP 8   /* candidates per phase-1 trip (2 / 4 / 8: 45.2 / 44.0 / 43.6 ms per late frame) */
+#endif
 constexpr int kBlock = 256;
 constexpr int kListCap = 64;          // entries per lane; a cell adds at most 32
 // The queue kernels are persistent grids of as many blocks as the device keeps resident (queue_grid below); the blocks
@@ -133,20 +136,25 @@ __device__ __forceinline__ void velpos_target(const Dev &d, uint32_t s, bool liv
             for (; ci < 27; ci++) {
                 const int xo = ci / 9 - 1, yo = (ci / 3) % 3 - 1, zo = ci % 3 - 1;
                 const CellRange cr = cell_range(d, ix + xo, iy + yo, iz + zo);
-                for (uint32_t k = 0; k < cr.cnt; k++) {
-                    const uint32_t j = cr.start + k;
-                    float rx, ry, rz;
-                    if (d.cur.p4) {                      // (wave-uniform) the packed copy: one 16-byte load instead of three
-                        const Pos3 pj = load_p4(d, d.cur, j);
-                        rx = pix - pj.x; ry = piy - pj.y; rz = piz - pj.z;
-                    } else {
-                        const Pos3 pj = load_pos(d, d.cur, j);
-                        rx = pix - pj.x; ry = piy - pj.y; rz = piz - pj.z;
+                // four candidates per trip, their loads issued together: one candidate per trip exposed a memory round trip per
+                // candidate, which five waves per SIMD do not hide (61 % of the VALU issue rate late in a dam break)
+                constexpr uint32_t kTrip = SPH_QUEUE_TRIP;
+                for (uint32_t k0 = 0; k0 < cr.cnt; k0 += kTrip) {
+                    Pos3 pj[kTrip];
+#pragma unroll
+                    for (uint32_t u = 0; u < kTrip; u++) {
+                        const uint32_t j = cr.start + (k0 + u < cr.cnt ? k0 + u : cr.cnt - 1u);
+                        pj[u] = d.cur.p4 ? load_p4(d, d.cur, j) : load_pos(d, d.cur, j);   // (wave-uniform) the packed copy: one 16-byte load
                     }
-                    const float r2 = (rx * rx + ry * ry) + rz * rz;
-                    if (j != s && r2 < d.h2_up) {        // superset of |r| < h (VelPos.compute:37,43)
+#pragma unroll
+                    for (uint32_t u = 0; u < kTrip; u++) {
+                        const uint32_t k = k0 + u, j = cr.start + k;
+                        const float rx = pix - pj[u].x, ry = piy - pj[u].y, rz = piz - pj[u].z;
+                        const float r2 = (rx * rx + ry * ry) + rz * rz;
+                        // branch-free append: always store at n, keep it only if the slot is a survivor (superset of |r| < h,
+                        // VelPos.compute:37,43); n <= kListCap - 32 on entry to a cell leaves room
                         list[(((n >> 1) * kBlock + tid) << 1) + (n & 1u)] = (uint16_t)((ci << 5) | k);
-                        n++;
+                        n += (k < cr.cnt && j != s && r2 < d.h2_up) ? 1u : 0u;
                     }
                 }
                 if (__any(n > (uint32_t)(kListCap - kMaxPerVoxel))) {            // next cell may not fit
@@ -154,14 +162,27 @@ __device__ __forceinline__ void velpos_target(const Dev &d, uint32_t s, bool liv
                     break;
                 }
             }
-            // phase 2: pair arithmetic over the survivors, same order
-            for (uint32_t e = 0; e < n; e++) {
+            // phase 2: pair arithmetic over the survivors, same order; the next survivor's fields are on their way meanwhile
+            // (two survivors per trip, as in the brick kernel: no gain here, 43.4 vs 43.6 ms per late frame)
+            struct Cand {
+                Pos3 p;
+                float4 rv;
+            };
+            auto fetch = [&](uint32_t e) {
                 const uint32_t ent = list[(((e >> 1) * kBlock + tid) << 1) + (e & 1u)];
                 const int c = (int)(ent >> 5);
                 const int xo = c / 9 - 1, yo = (c / 3) % 3 - 1, zo = c % 3 - 1;
                 const uint32_t cell = (uint32_t)(ix + xo) + (uint32_t)(iy + yo) * d.R + (uint32_t)(iz + zo) * d.R * d.R;
                 const uint32_t j = d.cell_start[cell] + (ent & 31u);
-                pair_force(d, j, pix, piy, piz, vix, viy, viz, p_i, f, false);
+                return Cand{d.cur.p4 ? load_p4(d, d.cur, j) : load_pos(d, d.cur, j), d.cur.rv[j]};   // :86-89
+            };
+            if (n) {
+                Cand a = fetch(0);
+                for (uint32_t e = 0; e < n; e++) {
+                    const Cand b = fetch(e + 1 < n ? e + 1 : e);
+                    pair_force_vals(d, pix - a.p.x, piy - a.p.y, piz - a.p.z, a.rv.x, a.rv.y, a.rv.z, a.rv.w, vix, viy, viz, p_i, f, true, false);
+                    a = b;
+                }
             }
         }
     }

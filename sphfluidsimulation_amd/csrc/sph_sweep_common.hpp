@@ -239,7 +239,7 @@ __device__ __forceinline__ void pair_force_vals(const Dev &d, float rx, float ry
     }
     const PairPre q = pair_pre<true>(d, rx, ry, rz, rho_j, vjx, vjy, vjz, vix, viy, viz, p_i, take);
     if (__builtin_expect(__any(pair_min_key(q) < kMagKeyMin), 0)) pair_finish<false>(q, f);
-    else pair_finish<true>(q, f);
+    else pair_finish_folded(d, q, f);                  // (not wild here: every value that reaches a select is finite or dropped)
 }
 
 __device__ __forceinline__ void pair_force(const Dev &d, uint32_t j, float pix, float piy, float piz,
