@@ -250,8 +250,14 @@ __global__ void __launch_bounds__(kBlock) k_cell_rank(Dev d, const uint2 *__rest
     const uint32_t start = d.cell_start[key];
     const uint32_t cnt = d.cell_start[key + 1] - start;
     uint32_t rank = 0;
-    for (uint32_t k = 0; k < cnt && rank < kMaxPerVoxel; k++)
-        rank += order_tmp[start + k].x < me.x ? 1u : 0u;
+    constexpr uint32_t kTrip = 8;                       // ids of a trip loaded together (crowded cells hold hundreds of members)
+    for (uint32_t k0 = 0; k0 < cnt && rank < kMaxPerVoxel; k0 += kTrip) {
+        uint32_t ids[kTrip];
+#pragma unroll
+        for (uint32_t u = 0; u < kTrip; u++) ids[u] = k0 + u < cnt ? order_tmp[start + k0 + u].x : 0xFFFFFFFFu;
+#pragma unroll
+        for (uint32_t u = 0; u < kTrip; u++) rank += ids[u] < me.x ? 1u : 0u;
+    }
     uint32_t slot = rank;
     if (rank >= kMaxPerVoxel) slot = kMaxPerVoxel + atomicAdd(&d.cell_count[key], 1u);
     d.order[start + slot] = me;

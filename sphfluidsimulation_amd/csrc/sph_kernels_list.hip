@@ -287,10 +287,16 @@ __global__ void __launch_bounds__(kBlock) k_velpos_list_changers(Dev d)
                                   bz >= t.c0z - 1 && bz <= t.c0z + 1;
             if (!recorded) {
                 const CellRange cr = cell_range(d, bx, by, bz);                  // bounds test :73 + the bucket row
-                for (uint32_t k = 0; k < cr.cnt; k++) {
-                    const Pos3 pj = load_p4(d, d.cur, cr.start + k);
-                    const float rx = t.px - pj.x, ry = t.py - pj.y, rz = t.pz - pj.z;
-                    if (__builtin_fmaf(rz, rz, __builtin_fmaf(ry, ry, rx * rx)) < d.h2_up) hit = true;   // superset of |r| < h
+                constexpr uint32_t kTrip = 4;                                    // loads of a trip issued together
+                for (uint32_t k0 = 0; k0 < cr.cnt; k0 += kTrip) {
+                    Pos3 pj[kTrip];
+#pragma unroll
+                    for (uint32_t u = 0; u < kTrip; u++) pj[u] = load_p4(d, d.cur, cr.start + (k0 + u < cr.cnt ? k0 + u : cr.cnt - 1u));
+#pragma unroll
+                    for (uint32_t u = 0; u < kTrip; u++) {
+                        const float rx = t.px - pj[u].x, ry = t.py - pj[u].y, rz = t.pz - pj[u].z;
+                        if (__builtin_fmaf(rz, rz, __builtin_fmaf(ry, ry, rx * rx)) < d.h2_up) hit = true;   // superset of |r| < h (a repeated last member changes nothing)
+                    }
                 }
             }
         }

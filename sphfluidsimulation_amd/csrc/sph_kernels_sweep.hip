@@ -21,6 +21,9 @@ namespace sph {
 #ifndef SPH_QUEUE_TRIP
 #define SPH_QUEUE_TRIP 8   /* candidates per phase-1 trip (2 / 4 / 8: 45.2 / 44.0 / 43.6 ms per late frame) */
 #endif
+#ifndef SPH_DQUEUE_TRIP
+#define SPH_DQUEUE_TRIP 4
+#endif
 constexpr int kBlock = 256;
 constexpr int kListCap = 64;          // entries per lane; a cell adds at most 32
 // The queue kernels are persistent grids of as many blocks as the device keeps resident (queue_grid below); the blocks
@@ -61,7 +64,7 @@ __device__ __forceinline__ uint32_t density_target(const Dev &d, uint32_t s)
                 const uint32_t code = (uint32_t)(((xo + 1) * 3 + (yo + 1)) * 3 + (zo + 1));
                 // four candidates per trip, their loads issued together (one 16-byte load each where the packed copy exists): a
                 // trip per candidate waited for one memory round trip per candidate
-                constexpr uint32_t kTrip = 4;
+                constexpr uint32_t kTrip = SPH_DQUEUE_TRIP;
                 for (uint32_t k0 = 0; k0 < cr.cnt; k0 += kTrip) {
                     Pos3 pj[kTrip];
 #pragma unroll
