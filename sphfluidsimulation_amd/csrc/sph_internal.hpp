@@ -174,6 +174,7 @@ enum Counter : int {
     kCntIrregular,      // last grid build saw a position outside [0,1] (or NaN): bins say nothing about positions
     kCntListTooLong,    // targets of the last recording density pass whose list exceeded nl_cap (their bricks scan)
     kCntQueueHead,      // next unclaimed entry of `queue`: the queue kernels deal it out in chunks of one block
+    kCntActiveHead,     // next unclaimed entry of active_list: the workgroups of k_velpos_brick claim their bricks one by one
     kCntCount
 };
 

@@ -221,6 +221,7 @@ __global__ void __launch_bounds__(kBlock) k_density_queue(Dev d)
 {
     __shared__ uint32_t s_q0;
     const uint32_t qlen = (uint32_t)d.counters[kCntQueue];
+    if (qlen == 0u) return;                            // (usual case: nothing was handed over)
     unsigned long long v = 0;
     for (uint32_t q0 = queue_claim(d, &s_q0); q0 < qlen; q0 = queue_claim(d, &s_q0)) {   // block-uniform
         const uint32_t q = q0 + threadIdx.x;
@@ -234,6 +235,7 @@ __global__ void __launch_bounds__(kBlock) k_velpos_queue(Dev d)
 {
     __shared__ uint32_t lds_list[(kListCap / 2) * kBlock];   // 32 KB: five blocks per CU (one word more would make it four)
     const uint32_t qlen = (uint32_t)d.counters[kCntQueue];
+    if (qlen == 0u) return;                            // (block-uniform)
     for (uint32_t q0 = queue_claim(d, lds_list); q0 < qlen; q0 = queue_claim(d, lds_list)) {   // block-uniform
         const uint32_t q = q0 + threadIdx.x;
         const bool live = q < qlen;
