@@ -239,7 +239,9 @@ int sph_get_stats(SphContext *ctx, SphStats *out);
 int sph_reset_stats(SphContext *ctx);
 int sph_synchronize(SphContext *ctx);
 
-/* Run on a caller-owned hipStream_t (e.g. torch's current stream) instead of the context's own. */
+/* Run on a caller-owned hipStream_t (e.g. torch's current stream) instead of the context's own.  Frames are still replayed from
+ * captured HIP graphs on it, except on the legacy default stream (NULL: it cannot be captured -- launches are issued one by one) and
+ * while the caller itself is capturing the stream (the launches join the caller's graph). */
 int sph_set_stream(SphContext *ctx, void *hip_stream);
 
 /* Which native libraries this process bound the engine to (diagnostics: a host that maps a second HIP runtime image --

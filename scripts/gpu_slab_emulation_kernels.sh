@@ -3,7 +3,7 @@
 N=${1:-8}; TAG=${2:-slab8}
 mkdir -p gpurun_out
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-GPU_MAX_HW_QUEUES=${HWQ:-4} timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$TAG -- python3 scripts/gpu_slab_emulation_profile.py $N > gpurun_out/prof_$TAG.log 2>&1 || { tail -5 gpurun_out/prof_$TAG.log; exit 1; }
+GPU_MAX_HW_QUEUES=${HWQ:-4} timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$TAG -- python3 scripts/gpu_slab_emulation_profile.py $N $OVERLAP > gpurun_out/prof_$TAG.log 2>&1 || { tail -5 gpurun_out/prof_$TAG.log; exit 1; }
 python3 - <<PY > gpurun_out/${TAG}_kernel_stats.txt
 import csv, glob
 for f in glob.glob("gpurun_out/prof_$TAG/*/*kernel_stats.csv"):

@@ -944,7 +944,14 @@ int sph_step(SphContext *c, float delta_time)
     grow_list_rows(c);
     if (frame_reports(c)) c->pol_issued++;
     // the first two frames after an upload run ungraphed: they allocate (neighbour lists) and settle the pointer parity
-    const bool graphed = c->graphs_enabled && c->own_stream && c->uploaded && c->frames_since_upload >= 2 && c->params.substeps > 0;
+    // ... and a stream the caller handed over (sph_set_stream) is captured like the context's own unless it is the legacy default
+    // stream (cannot be captured) or the caller is capturing it already (the launches then simply join the caller's graph)
+    bool stream_ok = c->own_stream;
+    if (!stream_ok && c->stream != nullptr) {
+        hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+        stream_ok = hipStreamIsCapturing(c->stream, &st) == hipSuccess && st == hipStreamCaptureStatusNone;
+    }
+    const bool graphed = c->graphs_enabled && stream_ok && c->uploaded && c->frames_since_upload >= 2 && c->params.substeps > 0;
     c->frames_since_upload++;
     if (!graphed) {
         c->dev.dt_ptr = nullptr;

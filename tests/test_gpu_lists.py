@@ -182,6 +182,35 @@ def test_frame_graph_replay_matches_issued_launches(oracle):
             s.OnDestroy()
 
 
+def test_adopted_stream_replays_graphs_too(oracle):
+    """sph_set_stream: on a stream the caller owns (here a torch side stream) frames are captured and replayed exactly as on the
+    context's own stream; on the legacy default stream (NULL, which cannot be captured) the launches are issued one by one.
+    Both bit-identical to the oracle."""
+    import torch
+    from sphfluidsimulation_amd.simulation import SphFluidSimulation
+    n, fill = 16384, 0.8
+    R = presets.scene_bucket_resolution(n)
+    pos0, vel0 = presets.dam_break(n, fill, seed=43, jitter=0.3)
+    dt = presets.bench_dt_frame(R) * 0.5
+    osim = oracle.OracleSimulation(oracle.derive(n, R, fill))
+    osim.upload(pos0, vel0)
+    for _ in range(7):
+        osim.Update(dt)
+    want = osim.download()
+    side = torch.cuda.Stream(device=0)
+    for handle, replays in ((side.cuda_stream, True), (0, False)):
+        sim = SphFluidSimulation(particleNumber=n, bucketResolution=R, damFillRate=fill, lists="always").Start(pos0, vel0)
+        try:
+            sim.set_stream(handle)
+            for _ in range(7):
+                sim.Update(dt)
+            for a, b in zip(sim.download(), want):
+                assert np.array_equal(_bits(a), _bits(b))
+            assert (sim.stats()["graph_replays"] >= 4) == replays
+        finally:
+            sim.OnDestroy()
+
+
 def test_one_million_particles_six_frames(oracle):
     """A mid-size end-to-end run the way a Unity caller would drive it: the reference's own initial condition on the
     device (InitParticles.compute Preset1 + simplex noise), six sph_step frames (lists from frame 2, graph replay from
