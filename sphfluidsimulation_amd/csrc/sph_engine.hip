@@ -79,6 +79,7 @@ void refresh_scalars(SphContext *c)
     {
         const double hs = (double)d.h * (1.0 + (double)c->nl_skin_frac);
         d.h2_list = nextafterf((float)(hs * hs * (1.0 + 1e-5)), INFINITY);
+        d.h2_stage = nextafterf((float)((double)d.h2_list * (1.0 + 1e-5)), INFINITY);
         d.skin_ok = (float)(0.9 * (double)c->nl_skin_frac * (double)d.h);
     }
     if (!c->slab) {

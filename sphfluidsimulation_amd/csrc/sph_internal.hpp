@@ -100,6 +100,7 @@ struct Dev {
     uint32_t *active_list; // [bricks]: the bricks the scanning kernel must take this sub-step (kNlUse)
     uint8_t *brick_state;  // [bricks]: kBrickUnlisted (set while building), kBrickActive (set per sub-step)
     float h2_list;         // pre-filter radius^2 of the building sub-step: (h + skin)^2, rounded up
+    float h2_stage;        // h2_list with a margin for fused multiply-adds: what phase 1 of the recording density pass stages
     float skin_ok;         // a brick is calm while the relative displacement bound stays <= this
 };
 

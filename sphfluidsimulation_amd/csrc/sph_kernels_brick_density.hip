@@ -10,7 +10,7 @@
 #define SPH_RECORD_CAP 928    /* tile of the recording pass and of k_velpos_tile (32 B per particle there: five workgroups per CU) */
 #endif
 #ifndef SPH_RECORD_MINWAVES
-#define SPH_RECORD_MINWAVES 6
+#define SPH_RECORD_MINWAVES 5     /* exact mode: 32 staged candidates per thread = 16 KB, five workgroups per CU */
 #endif
 #define SPH_BRICK_EMIT_DENSITY 1
 #ifndef SPH_SCAN_UNROLL
