@@ -11,7 +11,7 @@ PASS_B="SQ_INSTS_VALU_TRANS_F32 SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_
 i=0
 for P in "$PASS_A" "$PASS_B"; do
   i=$((i+1))
-  timeout -k 10 500 rocprofv3 --pmc $P --kernel-trace --output-format csv -d gpurun_out/sq_${TAG}_$i -- python3 bench.py --steps 3 --warmup 3 --no-cpu-baseline --no-extras $ARGS > gpurun_out/sq_${TAG}_$i.log 2>&1 || { tail -5 gpurun_out/sq_${TAG}_$i.log; exit 1; }
+  timeout -k 10 500 rocprofv3 --pmc $P --kernel-trace --output-format csv -d gpurun_out/sq_${TAG}_$i -- python3 bench.py --steps ${STEPS:-3} --warmup ${WARMUP:-3} --no-cpu-baseline --no-extras $ARGS > gpurun_out/sq_${TAG}_$i.log 2>&1 || { tail -5 gpurun_out/sq_${TAG}_$i.log; exit 1; }
 done
 python3 - <<PY
 import csv, glob, collections

@@ -23,5 +23,8 @@ if b[:, 5].max() > 0:      # k_velpos_tile (SPH_STAMPS=2): start -> rows known -
 for name, a, c in phases:
     dt = (b[:, c] - b[:, a])
     print(f"{name:16s} mean {dt.mean():9.0f} cycles  median {np.median(dt):9.0f}  p90 {np.percentile(dt, 90):9.0f}  ({dt.mean()/100:.1f} us at 100 MHz ticks?)")
+if b[:, 7].max() > 0:
+    ok = b[:, 7] > 0
+    print("s_memtime ticks per s_memrealtime tick (100 MHz): median %.2f -> clock of s_memtime %.0f MHz" % (np.median((b[ok, 4] - b[ok, 0]) / b[ok, 7]), 100 * np.median((b[ok, 4] - b[ok, 0]) / b[ok, 7])))
 span = b[:, 4].max() - b[:, 0].min()
 print("kernel span (ticks):", span)
