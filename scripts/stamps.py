@@ -15,10 +15,18 @@ buf = np.zeros((nb, 8), np.uint64)
 L = N.lib(); L.sph_debug_read_order.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
 assert L.sph_debug_read_order(sim._ctx, buf.ctypes.data_as(C.c_void_p), buf.nbytes) == 0
 b = buf[buf[:, 4] > 0].astype(np.int64)
+if b[:, 5].max() > 0:      # (k_velpos_tile: bricks that returned early hold the sort's leftovers -- keep the rows that look like stamps)
+    o = [0, 5, 6, 1, 2, 3, 4]
+    ok = np.ones(len(b), bool)
+    for a, c in zip(o[:-1], o[1:]):
+        ok &= b[:, a] <= b[:, c]
+    ok &= (b[:, 4] - b[:, 0]) < 4_000_000
+    b = b[ok]
 print("bricks with targets:", len(b), "of", nb)
 phases = (("setup", 0, 1), ("scan", 1, 2), ("phase2", 2, 3), ("integrate+store", 3, 4), ("total", 0, 4))
 if b[:, 5].max() > 0:      # k_velpos_tile (SPH_STAMPS=2): start -> rows known -> cell table + offsets -> tile staged -> target ready -> walked -> stored
-    phases = (("rows (+cell loads)", 0, 5), ("cell table + offsets", 5, 6), ("tile staged", 6, 1), ("entry rows + target", 1, 2), ("walk", 2, 3),
+    # (with brick records: start -> state known -> record in LDS -> tile staged -> ...)
+    phases = (("rows (+cell loads) | state", 0, 5), ("cell table + offsets | record", 5, 6), ("tile staged", 6, 1), ("entry rows + target", 1, 2), ("walk", 2, 3),
               ("integrate + store", 3, 4), ("total", 0, 4))
 for name, a, c in phases:
     dt = (b[:, c] - b[:, a])

@@ -211,7 +211,8 @@ static void ensure_lists(SphContext *c)
                     dalloc(c, &d.nl_ent, (size_t)d.nl_cap * ((n + 63) & ~(size_t)63)) == SPH_OK && dalloc(c, &d.nl_cnt, n) == SPH_OK &&
                     dalloc(c, &d.chunk_box, 6 * ((n + kChunkSlots - 1) / kChunkSlots)) == SPH_OK &&
                     dalloc(c, &d.active_list, bricks) == SPH_OK && dalloc(c, &d.queue2, n) == SPH_OK && dalloc(c, &d.brick_state, bricks) == SPH_OK &&
-                    dalloc(c, &d.cur.p4, n) == SPH_OK && dalloc(c, &d.nxt.p4, n) == SPH_OK;
+                    dalloc(c, &d.cur.p4, n) == SPH_OK && dalloc(c, &d.nxt.p4, n) == SPH_OK &&
+                    dalloc(c, &d.brick_rec, bricks * (size_t)kBrickRecWords) == SPH_OK;
     if (!ok) {
         while (c->allocs.size() > before) {
             (void)hipFree(c->allocs.back());
@@ -226,6 +227,7 @@ static void ensure_lists(SphContext *c)
         d.active_list = nullptr;
         d.queue2 = nullptr;
         d.brick_state = nullptr;
+        d.brick_rec = nullptr;
         d.cur.p4 = d.nxt.p4 = nullptr;
         c->nl_enabled = false;
         c->nl_unavailable = true;     // (sticky: a later sph_set_params must not try the multi-GB allocation again)

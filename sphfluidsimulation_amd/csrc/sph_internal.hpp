@@ -102,6 +102,9 @@ struct Dev {
     float h2_list;         // pre-filter radius^2 of the building sub-step: (h + skin)^2, rounded up
     float h2_stage;        // h2_list with a margin for fused multiply-adds: what phase 1 of the recording density pass stages
     float skin_ok;         // a brick is calm while the relative displacement bound stays <= this
+    uint32_t *brick_rec;   // [bricks][kBrickRecWords]: the set-up of every brick's LDS tile (cell table after the offset scan, owned
+                           //   rows), written by the recording density pass and read back by k_velpos_tile in the S sub-steps of the
+                           //   frame -- the tile is a function of cell_start alone, and the grid is frozen for the frame
 };
 
 enum : uint32_t { kNlOff = 0, kNlBuild = 1, kNlUse = 2 };
@@ -112,6 +115,16 @@ enum : uint8_t { kBrickUnlisted = 1, kBrickActive = 2, kBrickEmpty = 4 };   // (
 constexpr int kChunkSlots = SPH_CHUNK_SLOTS;      // consecutive slots per displacement box (a power of two <= 64)
 constexpr uint32_t kNlSlotBits = 27;             // entry = cell code << 27 | slot
 constexpr int kNlBX = 4, kNlBY = 4, kNlBZ = 4;   // brick shape of the VelPos kernels (sph_kernels_brick_velpos.hip)
+// A brick record (Dev::brick_rec; 4x4x4-cell bricks with halo 1: 6^3 = 216 tile cells, 16 owned rows), in dwords:
+//   [2c], [2c + 1]       tile cell c (z fastest): LDS offset | listed count << 16, first global slot   (one 8-byte load per thread)
+//   [kBrickRecRows + r]  first slot of owned row r;   [kBrickRecPref + r]  targets in the rows before r (r = 16: all of them)
+//   [kBrickRecStatus]    bit 0: the record is valid (the whole brick fits ONE tile); bits 8..: listed particles of the tile
+//   [kBrickRecSrc + i]   global slot of the particle with tile index i (i < kBrickRecSrcCap)
+constexpr int kBrickRecCells = (kNlBX + 2) * (kNlBY + 2) * (kNlBZ + 2);
+constexpr int kBrickRecRows = 2 * kBrickRecCells, kBrickRecPref = kBrickRecRows + kNlBY * kNlBZ,
+              kBrickRecStatus = kBrickRecPref + kNlBY * kNlBZ + 1, kBrickRecSrc = 512, kBrickRecSrcCap = 1024,
+              kBrickRecWords = kBrickRecSrc + kBrickRecSrcCap;
+static_assert(kBrickRecStatus < kBrickRecSrc, "a brick record fits its stride");
 
 __device__ __forceinline__ uint32_t *nl_entries(const Dev &d, uint32_t slot)   // entry e of the slot: [e * kWave]
 {
