@@ -210,7 +210,7 @@ static void ensure_lists(SphContext *c)
     const bool ok = binned &&
                     dalloc(c, &d.nl_ent, (size_t)d.nl_cap * ((n + 63) & ~(size_t)63)) == SPH_OK && dalloc(c, &d.nl_cnt, n) == SPH_OK &&
                     dalloc(c, &d.chunk_box, 6 * ((n + kChunkSlots - 1) / kChunkSlots)) == SPH_OK &&
-                    dalloc(c, &d.active_list, bricks) == SPH_OK && dalloc(c, &d.queue2, n) == SPH_OK && dalloc(c, &d.brick_state, bricks) == SPH_OK &&
+                    dalloc(c, &d.active_list, bricks) == SPH_OK && dalloc(c, &d.queue2, n) == SPH_OK && dalloc(c, &d.brick_state, bricks + 4) == SPH_OK &&
                     dalloc(c, &d.cur.p4, n) == SPH_OK && dalloc(c, &d.nxt.p4, n) == SPH_OK &&
                     dalloc(c, &d.brick_rec, bricks * (size_t)kBrickRecWords) == SPH_OK;
     if (!ok) {

@@ -75,6 +75,7 @@ struct PairPre {
     float ncp;             // p_i + p_j          :93
     float nvx, nvy, nvz;   // v_j - v_i          :94
     bool in_p, ok;
+    bool sc_small;         // sc < 2^-27: a nonzero sc * r component may lie below the numerator window (pair_window_by_operands)
 };
 
 template <bool FAST>
@@ -91,6 +92,7 @@ __device__ __forceinline__ PairPre pair_pre(const Dev &d, float rx, float ry, fl
     const float diff_r = h - q.abs_r;                                            // :36
     q.in_p = (epsilon < diff_r) && (epsilon < q.abs_r);                          // :37
     const float sc = d.c_over_h6 * ((diff_r * diff_r) * diff_r);
+    q.sc_small = sc < 0x1p-27f;
     q.ngx = sc * rx; q.ngy = sc * ry; q.ngz = sc * rz;
     q.ncp = p_i + p_j;                                                           // :93
     q.gv = q.abs_r < h ? d.c_over_h6 * (h - q.abs_r) : 0.0f;                     // :43
@@ -103,6 +105,22 @@ __device__ __forceinline__ uint32_t pair_min_key(const PairPre &q)
 {
     return umin3(umin3(mag_key(q.ngx), mag_key(q.ngy), mag_key(q.ngz)), umin3(mag_key(q.nvx), mag_key(q.nvy), mag_key(q.nvz)),
                  mag_key(q.ncp));
+}
+
+// The numerator window of sph_fastdiv.hpp from the OPERANDS instead of the seven numerators (pair_min_key: 7 shifts, 3 min3 and
+// a compare per pair -- integer instructions cost 4.3 cycles per wave on gfx950 against 2.9 for a multiply-add, ~13 % of a pair).
+// If no position component of the two particles is nonzero below 2^-40 and no velocity component or pressure nonzero below 2^-60
+// (operand_tiny: tested once per PARTICLE by a kernel that stages its candidates), then
+//   v_j - v_i, p_i + p_j   are 0 or >= 2^-60 * 2^-24 = 2^-84 in magnitude (a difference of two floats is a multiple of the smaller ulp);
+//   r = pos_i - pos_j      has components that are 0 or >= 2^-40 * 2^-23 = 2^-63, so sc * r is 0 or >= 2^-90 when sc >= 2^-27
+// and only `in_p && sc < 2^-27` is left to test per pair (with in_p false every quotient by |r| is dropped by its select).  The
+// upper end of the window is the wild flags' as before.
+__device__ __forceinline__ bool operand_tiny(const Dev &d, float x, float y, float z, float rho, float vx, float vy, float vz)
+{
+    constexpr uint32_t kKeyPos = ((127u - 40u) << 24) - 1u, kKeyVel = ((127u - 60u) << 24) - 1u;   // mag_key(2^-40), mag_key(2^-60)
+    const float p = d.gas_const * (rho - d.rest_density);                        // :61 / :87, the same operations
+    return umin3(mag_key(x), mag_key(y), mag_key(z)) < kKeyPos ||
+           umin3(umin3(mag_key(vx), mag_key(vy), mag_key(vz)), mag_key(p), 0xFFFFFFFFu) < kKeyVel;
 }
 
 template <bool SHARED>

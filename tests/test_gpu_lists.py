@@ -298,6 +298,47 @@ def test_scene_size_120_frames_default_context(oracle):
         sim.OnDestroy()
 
 
+@pytest.mark.parametrize("what", ["velocity", "position", "pressure"])
+def test_tiny_operands_take_the_plain_divisions(oracle, what):
+    """k_velpos_tile decides from per-particle operand tests whether its shared-reciprocal quotients are safe
+    (sph_sweep_common.hpp, operand_tiny): a velocity component of 1e-30, a position component of 1e-20 or a pressure of
+    ~1e-21 (gas constant 1e-20) puts numerators below the window, and the workgroups that stage
+    such a particle must fall back to IEEE division -- bit-identical to the oracle and to the scanning kernels either way."""
+    n, fill = 65536, 0.8
+    R = presets.scene_bucket_resolution(n)
+    pos0, vel0 = presets.dam_break(n, fill, seed=23, jitter=0.3)
+    rng = np.random.default_rng(5)
+    vel0[:, :3] = rng.standard_normal((n, 3)).astype(f32) * f32(0.01)
+    pick = rng.choice(n, 4096, replace=False)
+    kw = {}
+    if what == "velocity":
+        vel0[pick[:2048], 0] = f32(1e-30)
+        vel0[pick[2048:], 2] = f32(-3e-33)
+        vel0[pick[:64], 1] = f32(1e-42)       # denormal
+    elif what == "position":
+        # on the x = 0 and z = 0 walls: nonzero components below 2^-40 (the clamp keeps them in the box)
+        pos0[pick[:2048], 0] = f32(1e-20)
+        pos0[pick[2048:], 2] = f32(3e-25)
+        vel0[pick, :3] = 0
+    else:
+        kw = dict(gasConstant=1e-20)          # every pressure k * (rho - rho0) ~ 1e-21 < 2^-60: every workgroup falls back
+    dt = presets.bench_dt_frame(R) * 0.05
+    frames = 2
+    (on, st_on), (off, _) = _run_pair(n, R, fill, pos0, vel0, frames, dt, **kw)
+    for a, b in zip(on, off):
+        assert np.array_equal(_bits(a), _bits(b))
+    d = oracle.derive(n, R, fill)
+    if kw:
+        d = oracle.derive(n, R, fill, gas_constant=kw["gasConstant"])
+    osim = oracle.OracleSimulation(d)
+    osim.upload(pos0, vel0)
+    for _ in range(frames):
+        osim.Update(dt)
+    for a, b in zip(on, osim.download()):
+        assert np.array_equal(_bits(a), _bits(b))
+    assert st_on["listed_target_substeps"] > 0.5 * n * frames * 5
+
+
 @pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("SPH_FUZZ_SEEDS", "10"))))
 def test_random_configurations_all_paths(oracle, seed):
     """Random sizes, grids, fill rates, speeds, time steps, inspector scalars and list modes: whatever mixture of list,
