@@ -97,6 +97,8 @@ typedef struct SphParams {
 #define SPH_FLAG_GLOBAL_LISTS 256u /* diagnostic: the brick kernels record lists of global slots and k_velpos_list gathers the
                                       candidates through L1/L2 (rounds 1-2) instead of lists of LDS tile indices walked by
                                       k_velpos_tile; same bits, slower */
+#define SPH_FLAG_TILE_SLOTS_ONE 512u  /* diagnostic: k_velpos_tile compiled for whole-brick records only (default: picked from the particles per cell) */
+#define SPH_FLAG_TILE_SLOTS_TWO 1024u /* diagnostic: k_velpos_tile compiled for the records of halved bricks too (config C4's regime) */
 #define SPH_FLAG_NO_GRAPHS 8u   /* diagnostic: sph_step issues its ~60 launches every frame instead of replaying a HIP graph */
 
 /* Values of the uniforms the reference pushes through ShaderIDs.cs:5-32. */

@@ -24,6 +24,8 @@ SPH_FLAG_PEER_COPIES = 32
 SPH_FLAG_NO_OVERLAP = 64
 SPH_FLAG_FORCE_TWO_PASS = 128
 SPH_FLAG_GLOBAL_LISTS = 256
+SPH_FLAG_TILE_SLOTS_ONE = 512
+SPH_FLAG_TILE_SLOTS_TWO = 1024
 SPH_COMM_ID_BYTES = 128
 SPH_SLAB_UPDATE_RHO = 0
 SPH_SLAB_UPDATE_POSVEL = 1

@@ -1,5 +1,6 @@
 // Host side of libsph_hip.so: context, device memory, the frame schedule of
 // SphFluidSimulation.cs::Update (:96-102) and the C ABI declared in include/sph_hip.h.
+#include <algorithm>
 #include "sph_context.hpp"
 
 #include <limits.h>
@@ -72,6 +73,15 @@ void refresh_scalars(SphContext *c)
     d.prec = p.precision;
     d.fast = p.exact_order == 0u ? 1u : 0u;
     d.nl_tile = (p.flags & SPH_FLAG_GLOBAL_LISTS) ? 0u : 1u;
+    {
+        // k_velpos_tile with one record slot or two (sph_brick_impl.inc): a brick is halved when the listed particles of its
+        // halo-1 box (216 cells) exceed the 928-particle tile -- expected where the occupied cells hold more than ~4 particles
+        // (the dam fills `fill` x 0.9 of the box; 3.7 per cell at the scene's R, 5.5 under the R <= 256 cap of config C4)
+        const double per_cell = (double)dv.particle_count / ((double)d.num_cells * 0.9 * (double)std::min(std::max(p.dam_fill_rate, 0.05f), 1.0f));
+        d.tile_slots = per_cell * 216.0 > 0.95 * 928.0 ? 2u : 1u;
+        if (p.flags & SPH_FLAG_TILE_SLOTS_ONE) d.tile_slots = 1u;
+        if (p.flags & SPH_FLAG_TILE_SLOTS_TWO) d.tile_slots = 2u;
+    }
     // neighbour lists: skin = nl_skin_frac * h; pre-filter radius (h + skin)^2 rounded up like h2_up; a brick is calm
     // while its relative-displacement bound stays below 90 % of the skin (the rest absorbs fp32 rounding of the bound)
     c->nl_enabled = d.use_bricks && !(p.flags & SPH_FLAG_NO_LISTS) && d.R <= 256u && !c->nl_unavailable;
@@ -212,7 +222,7 @@ static void ensure_lists(SphContext *c)
                     dalloc(c, &d.chunk_box, 6 * ((n + kChunkSlots - 1) / kChunkSlots)) == SPH_OK &&
                     dalloc(c, &d.active_list, bricks) == SPH_OK && dalloc(c, &d.queue2, n) == SPH_OK && dalloc(c, &d.brick_state, bricks + 4) == SPH_OK &&
                     dalloc(c, &d.cur.p4, n) == SPH_OK && dalloc(c, &d.nxt.p4, n) == SPH_OK &&
-                    dalloc(c, &d.brick_rec, bricks * (size_t)kBrickRecWords) == SPH_OK;
+                    dalloc(c, &d.brick_rec, bricks * (size_t)(kBrickRecSlots * kBrickRecWords)) == SPH_OK;
     if (!ok) {
         while (c->allocs.size() > before) {
             (void)hipFree(c->allocs.back());

@@ -102,6 +102,7 @@ struct Dev {
     float h2_list;         // pre-filter radius^2 of the building sub-step: (h + skin)^2, rounded up
     float h2_stage;        // h2_list with a margin for fused multiply-adds: what phase 1 of the recording density pass stages
     float skin_ok;         // a brick is calm while the relative displacement bound stays <= this
+    uint32_t tile_slots;   // which k_velpos_tile the launcher takes: 1 = whole-brick records, 2 = the records of halved bricks too
     uint32_t *brick_rec;   // [bricks][kBrickRecWords]: the set-up of every brick's LDS tile (cell table after the offset scan, owned
                            //   rows), written by the recording density pass and read back by k_velpos_tile in the S sub-steps of the
                            //   frame -- the tile is a function of cell_start alone, and the grid is frozen for the frame
@@ -118,12 +119,14 @@ constexpr int kNlBX = 4, kNlBY = 4, kNlBZ = 4;   // brick shape of the VelPos ke
 // A brick record (Dev::brick_rec; 4x4x4-cell bricks with halo 1: 6^3 = 216 tile cells, 16 owned rows), in dwords:
 //   [2c], [2c + 1]       tile cell c (z fastest): LDS offset | listed count << 16, first global slot   (one 8-byte load per thread)
 //   [kBrickRecRows + r]  first slot of owned row r;   [kBrickRecPref + r]  targets in the rows before r (r = 16: all of them)
-//   [kBrickRecStatus]    bit 0: the record is valid (the whole brick fits ONE tile); bits 8..: listed particles of the tile
+//   [kBrickRecStatus]    bit 0: the record is valid; bits 1..3: cells along x of its range (4 = the whole brick, 2 = a half);
+//                        bits 8..: listed particles of the tile
+// kBrickRecSlots records per brick: [0] the whole brick, or its left half when the whole does not fit one tile; [1] the right half.
 //   [kBrickRecSrc + i]   global slot of the particle with tile index i (i < kBrickRecSrcCap)
 constexpr int kBrickRecCells = (kNlBX + 2) * (kNlBY + 2) * (kNlBZ + 2);
 constexpr int kBrickRecRows = 2 * kBrickRecCells, kBrickRecPref = kBrickRecRows + kNlBY * kNlBZ,
               kBrickRecStatus = kBrickRecPref + kNlBY * kNlBZ + 1, kBrickRecSrc = 512, kBrickRecSrcCap = 1024,
-              kBrickRecWords = kBrickRecSrc + kBrickRecSrcCap;
+              kBrickRecWords = kBrickRecSrc + kBrickRecSrcCap, kBrickRecSlots = 2;
 static_assert(kBrickRecStatus < kBrickRecSrc, "a brick record fits its stride");
 
 __device__ __forceinline__ uint32_t *nl_entries(const Dev &d, uint32_t slot)   // entry e of the slot: [e * kWave]

@@ -298,6 +298,40 @@ def test_scene_size_120_frames_default_context(oracle):
         sim.OnDestroy()
 
 
+@pytest.mark.parametrize("R", [47, 38])
+def test_tile_record_slots_agree(oracle, R):
+    """k_velpos_tile takes a brick's tile set-up from the records the density pass wrote (whole brick, or -- where ~6
+    particles per cell make the halo-1 box overflow the tile, R = 38 here, config C4's regime -- its two halves).  Both
+    instantiations (one record slot: halved bricks are set up from cell_start; two slots) agree bit for bit with each other,
+    with the scanning kernels and with the oracle."""
+    from sphfluidsimulation_amd.simulation import SphFluidSimulation
+    n, fill = 262144, 0.8
+    pos0, vel0 = presets.dam_break(n, fill, seed=29, jitter=0.3)
+    dt = presets.bench_dt_frame(R) * 0.1
+    frames = 2
+    outs = []
+    for slots, lists in ((1, "always"), (2, "always"), (0, False)):
+        sim = SphFluidSimulation(particleNumber=n, bucketResolution=R, damFillRate=fill, lists=lists, tile_slots=slots).Start(pos0, vel0)
+        try:
+            sim.reset_stats()
+            for _ in range(frames):
+                sim.Update(dt)
+            outs.append((sim.download(), sim.stats()))
+        finally:
+            sim.OnDestroy()
+    for other, _ in outs[1:]:
+        for a, b in zip(outs[0][0], other):
+            assert np.array_equal(_bits(a), _bits(b))
+    osim = oracle.OracleSimulation(oracle.derive(n, R, fill))
+    osim.upload(pos0, vel0)
+    for _ in range(frames):
+        osim.Update(dt)
+    for a, b in zip(outs[0][0], osim.download()):
+        assert np.array_equal(_bits(a), _bits(b))
+    for k in (0, 1):
+        assert outs[k][1]["listed_target_substeps"] > 0.8 * n * frames * 5
+
+
 @pytest.mark.parametrize("what", ["velocity", "position", "pressure"])
 def test_tiny_operands_take_the_plain_divisions(oracle, what):
     """k_velpos_tile decides from per-particle operand tests whether its shared-reciprocal quotients are safe
