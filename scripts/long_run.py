@@ -10,9 +10,10 @@ lists = (sys.argv[4] != "nolists") if len(sys.argv) > 4 else True
 precision = int(sys.argv[5]) if len(sys.argv) > 5 else 0
 skin = float(sys.argv[6]) if len(sys.argv) > 6 else 0.0
 exact = (sys.argv[7] != "tolerance") if len(sys.argv) > 7 else True
+chunk_boxes = (sys.argv[8] == "chunkboxes") if len(sys.argv) > 8 else False
 R = presets.scene_bucket_resolution(n)
 pos0, vel0 = presets.dam_break(n, 0.8, 1)
-sim = SphFluidSimulation(particleNumber=n, bucketResolution=R, damFillRate=0.8, profile=True, lists=lists, precision=precision, list_skin=skin, exact_order=exact).Start(pos0, vel0)
+sim = SphFluidSimulation(particleNumber=n, bucketResolution=R, damFillRate=0.8, profile=True, lists=lists, precision=precision, list_skin=skin, exact_order=exact, chunk_boxes=chunk_boxes).Start(pos0, vel0)
 dt = presets.bench_dt_frame(R)
 for f0 in range(0, frames, chunk):
     sim.reset_stats()

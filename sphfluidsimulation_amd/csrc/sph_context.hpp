@@ -91,6 +91,7 @@ struct SphContext {
     bool ext_sem_timeline = false;
     bool uploaded = false, grid_valid = false;
     int substeps_since_upload = 0;
+    int substep_in_frame = 0;         // sub-steps issued since the last grid build (parity of the per-brick displacement boxes)
     float dt_last = 0.0f;
     uint64_t frames = 0, substeps = 0;
     // profiling

@@ -73,6 +73,7 @@ void refresh_scalars(SphContext *c)
     d.prec = p.precision;
     d.fast = p.exact_order == 0u ? 1u : 0u;
     d.nl_tile = (p.flags & SPH_FLAG_GLOBAL_LISTS) ? 0u : 1u;
+    d.box_mode = c->slab || (p.flags & SPH_FLAG_CHUNK_BOXES) ? 0u : 1u;   // (ghosts move without being integrated by their slab: chunk boxes there)
     {
         // k_velpos_tile with one record slot or two (sph_brick_impl.inc): a brick is halved when the listed particles of its
         // halo-1 box (216 cells) exceed the 928-particle tile -- expected where the occupied cells hold more than ~4 particles
@@ -222,7 +223,8 @@ static void ensure_lists(SphContext *c)
                     dalloc(c, &d.chunk_box, 6 * ((n + kChunkSlots - 1) / kChunkSlots)) == SPH_OK &&
                     dalloc(c, &d.active_list, bricks) == SPH_OK && dalloc(c, &d.queue2, n) == SPH_OK && dalloc(c, &d.brick_state, bricks + 4) == SPH_OK &&
                     dalloc(c, &d.cur.p4, n) == SPH_OK && dalloc(c, &d.nxt.p4, n) == SPH_OK &&
-                    dalloc(c, &d.brick_rec, bricks * (size_t)(kBrickRecSlots * kBrickRecWords)) == SPH_OK;
+                    dalloc(c, &d.brick_rec, bricks * (size_t)(kBrickRecSlots * kBrickRecWords)) == SPH_OK &&
+                    dalloc(c, &d.dbox, 12 * bricks) == SPH_OK && dalloc(c, &d.cbox, 12 * bricks) == SPH_OK;
     if (!ok) {
         while (c->allocs.size() > before) {
             (void)hipFree(c->allocs.back());
@@ -238,6 +240,8 @@ static void ensure_lists(SphContext *c)
         d.queue2 = nullptr;
         d.brick_state = nullptr;
         d.brick_rec = nullptr;
+        d.dbox = nullptr;
+        d.cbox = nullptr;
         d.cur.p4 = d.nxt.p4 = nullptr;
         c->nl_enabled = false;
         c->nl_unavailable = true;     // (sticky: a later sph_set_params must not try the multi-GB allocation again)
@@ -254,6 +258,7 @@ int do_bucket_generation(SphContext *c)
     c->dev.use_lists = c->nl_enabled && c->nl_allocated && c->pol_on ? 1u : 0u;
     c->nl_fresh = c->dev.use_lists != 0u;
     c->nl_recorded = false;
+    c->substep_in_frame = 0;
     {
         PassTimer t(c, 0);
         launch_grid_build(c->dev, c->stream);
@@ -288,6 +293,7 @@ static void velpos_fields(SphContext *c, float dt)
     c->dev.dt = dt;
     c->dev.nl_mode = c->dev.use_lists && c->nl_recorded ? kNlUse : kNlOff;
     c->dev.nl_still = c->nl_fresh ? 1u : 0u;   // first sub-step since the grid build: the recorded positions still stand
+    c->dev.box_par = (uint32_t)c->substep_in_frame & 1u;
     c->nl_fresh = false;              // positions move: a later density pass of this frame must not record
 }
 
@@ -314,6 +320,7 @@ static void velpos_done(SphContext *c, float dt)
     c->dev.wild_v_cur ^= 1u;
     c->substeps++;
     c->substeps_since_upload++;
+    c->substep_in_frame++;
     c->dt_last = dt;
 }
 
@@ -942,6 +949,7 @@ static void account_replayed_frame(SphContext *c, const SphContext::FrameGraph &
     c->frames++;
     c->substeps += S;
     c->substeps_since_upload += (int)S;
+    c->substep_in_frame = (int)S;
     c->dt_last = dt;
 }
 
@@ -978,6 +986,7 @@ int sph_step(SphContext *c, float delta_time)
     memcpy(&start, &c->dev, sizeof(Dev));
     start.nl_mode = 0;                // per-launch scratch
     start.nl_still = 0;
+    start.box_par = 0;
     const bool lists_on = c->nl_enabled && c->nl_allocated && c->pol_on;
     if (!g.exec || g.substeps != c->params.substeps || g.lists_on != lists_on || memcmp(&g.start, &start, sizeof(Dev)) != 0) {
         if (g.exec) (void)hipGraphExecDestroy(g.exec);
@@ -987,7 +996,7 @@ int sph_step(SphContext *c, float delta_time)
         memcpy(&dev_before, &c->dev, sizeof(Dev));
         const bool grid_valid = c->grid_valid, fresh = c->nl_fresh, recorded = c->nl_recorded;
         const uint64_t frames = c->frames, substeps = c->substeps;
-        const int since = c->substeps_since_upload;
+        const int since = c->substeps_since_upload, in_frame = c->substep_in_frame;
         bool ok = hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
         int rc = ok ? issue_frame(c, dt) : SPH_OK;
         if (ok) ok = hipStreamEndCapture(c->stream, &graph) == hipSuccess && graph && rc == SPH_OK;
@@ -1002,6 +1011,7 @@ int sph_step(SphContext *c, float delta_time)
         c->frames = frames;
         c->substeps = substeps;
         c->substeps_since_upload = since;
+        c->substep_in_frame = in_frame;
         if (!ok) {                    // no graphs on this system / for this launch sequence: keep issuing the launches
             (void)hipGetLastError();
             if (g.exec) (void)hipGraphExecDestroy(g.exec);

@@ -102,6 +102,14 @@ struct Dev {
     float h2_list;         // pre-filter radius^2 of the building sub-step: (h + skin)^2, rounded up
     float h2_stage;        // h2_list with a margin for fused multiply-adds: what phase 1 of the recording density pass stages
     float skin_ok;         // a brick is calm while the relative displacement bound stays <= this
+    // Per-brick displacement boxes (Dev::box_mode; sph_kernels_list.hip): every kernel that integrates a target adds the target's
+    // displacement of THIS sub-step to the range of its bin's brick (dbox, atomic min / max on order-preserving keys);
+    // k_brick_activity sums the ranges over the sub-steps of the frame (cbox) -- a superset of the range of the displacements
+    // since the grid build, without a pass over all positions (k_chunk_box) per sub-step.
+    uint32_t box_mode;     // 1: per-brick boxes; 0: k_chunk_box + chunk boxes (z-slab contexts: ghosts move without being integrated here)
+    uint32_t box_par;      // parity of the sub-step in flight within its frame: which half of dbox / cbox it writes
+    uint32_t *dbox;        // [2][6][bricks]: keys of min x,y,z / max x,y,z of the displacements of one sub-step
+    float *cbox;           // [2][6][bricks]: the ranges summed over the sub-steps so far
     uint32_t tile_slots;   // which k_velpos_tile the launcher takes: 1 = whole-brick records, 2 = the records of halved bricks too
     uint32_t *brick_rec;   // [bricks][kBrickRecWords]: the set-up of every brick's LDS tile (cell table after the offset scan, owned
                            //   rows), written by the recording density pass and read back by k_velpos_tile in the S sub-steps of the
@@ -128,6 +136,15 @@ constexpr int kBrickRecRows = 2 * kBrickRecCells, kBrickRecPref = kBrickRecRows 
               kBrickRecStatus = kBrickRecPref + kNlBY * kNlBZ + 1, kBrickRecSrc = 512, kBrickRecSrcCap = 1024,
               kBrickRecWords = kBrickRecSrc + kBrickRecSrcCap, kBrickRecSlots = 2;
 static_assert(kBrickRecStatus < kBrickRecSrc, "a brick record fits its stride");
+
+// order-preserving key of a float for integer atomic min / max (NaN sorts above +inf or below -inf: it reaches the decoder)
+__device__ __forceinline__ uint32_t float_key(float f)
+{
+    const uint32_t b = __float_as_uint(f);
+    return b ^ ((b >> 31) ? 0xFFFFFFFFu : 0x80000000u);
+}
+__device__ __forceinline__ float key_float(uint32_t k) { return __uint_as_float(k ^ ((k >> 31) ? 0x80000000u : 0xFFFFFFFFu)); }
+constexpr uint32_t kBoxKeyEmptyLo = 0xFFFFFFFFu, kBoxKeyEmptyHi = 0u;   // a range nobody has added to
 
 __device__ __forceinline__ uint32_t *nl_entries(const Dev &d, uint32_t slot)   // entry e of the slot: [e * kWave]
 {

@@ -88,6 +88,57 @@ __global__ void __launch_bounds__(kBlock) k_brick_activity(Dev d, int nbx, int n
     float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
     bool own_nonempty = false;
     if (d.nl_still) lo[0] = lo[1] = lo[2] = hi[0] = hi[1] = hi[2] = 0.0f;   // first sub-step: every displacement is zero, no chunk boxes yet
+    if (d.box_mode) {
+        // Per-brick boxes (launch-uniform): lane l < 27 looks at neighbour brick l.  Its range so far = the sum of its per-sub-step
+        // ranges (cbox of the previous sub-step + the dbox the previous sub-step's kernels filled): the displacement of a particle
+        // since the grid build is the sum of its sub-step displacements, so it lies in the sum of the ranges.  The wave writes its
+        // OWN brick's new sum and resets its own dbox for the kernels of this sub-step (the other parity: nobody reads it now).
+        const uint32_t nb = d.n_bricks, par = d.box_par, prev = par ^ 1u;
+        float mlo[3] = {0.0f, 0.0f, 0.0f}, mhi[3] = {0.0f, 0.0f, 0.0f};    // (own brick, kept by lane 13)
+        if (!d.nl_still && lane < 27) {
+            const int bx = b % nbx + lane % 3 - 1, by = (b / nbx) % nby + (lane / 3) % 3 - 1, bz = b / (nbx * nby) + lane / 9 - 1;
+            const int nbz = (int)nl_bricks_z(d.R);
+            if (bx >= 0 && by >= 0 && bz >= 0 && bx < nbx && by < nby && bz < nbz) {
+                const uint32_t n = (uint32_t)bx + (uint32_t)nbx * ((uint32_t)by + (uint32_t)nby * (uint32_t)bz);
+                const uint32_t *dk = d.dbox + (size_t)prev * 6u * nb + n;
+                const float *ck = d.cbox + (size_t)prev * 6u * nb + n;
+#pragma unroll
+                for (int a = 0; a < 3; a++) {
+                    const uint32_t kl = dk[(size_t)a * nb], kh = dk[(size_t)(3 + a) * nb];
+                    float l = ck[(size_t)a * nb], h = ck[(size_t)(3 + a) * nb];
+                    mlo[a] = l; mhi[a] = h;
+                    // (a brick nobody was integrated in holds no particle -- every particle is some kernel's target in every
+                    // sub-step -- and stays out of the union)
+                    if (kl != kBoxKeyEmptyLo || kh != kBoxKeyEmptyHi) {
+                        mlo[a] = lo[a] = l + key_float(kl);
+                        mhi[a] = hi[a] = h + key_float(kh);
+                    }
+                }
+            }
+        }
+        if (exists && lane == 13) {                    // the centre: this wave's own brick
+#pragma unroll
+            for (int a = 0; a < 3; a++) {
+                d.cbox[(size_t)par * 6u * nb + (size_t)a * nb + (uint32_t)b] = mlo[a];
+                d.cbox[(size_t)par * 6u * nb + (size_t)(3 + a) * nb + (uint32_t)b] = mhi[a];
+                d.dbox[(size_t)par * 6u * nb + (size_t)a * nb + (uint32_t)b] = kBoxKeyEmptyLo;
+                d.dbox[(size_t)par * 6u * nb + (size_t)(3 + a) * nb + (uint32_t)b] = kBoxKeyEmptyHi;
+            }
+        }
+        if (d.nl_still) {
+            // which bricks hold targets: from the rows of its bins, once per frame (later sub-steps keep the flag)
+            if (lane < kNlBY * kNlBZ) {
+                const int cy = y0 + lane % kNlBY, cz = z0 + lane / kNlBY;
+                if (cy < R && cz < R && x0 < R) {
+                    const int xb = x0 + kNlBX - 1 < R - 1 ? x0 + kNlBX - 1 : R - 1;
+                    const uint32_t rk = (uint32_t)cy * d.R + (uint32_t)cz * d.R * d.R;
+                    own_nonempty = d.cell_start[rk + (uint32_t)xb + 1u] > d.cell_start[rk + (uint32_t)x0];
+                }
+            }
+        } else {
+            own_nonempty = !(d.brick_state[b] & kBrickEmpty);
+        }
+    } else
     if (lane < kRY * kRZ) {
         const int cy = y0 - 1 + lane % kRY, cz = z0 - 1 + lane / kRY;
         if (cy >= 0 && cz >= 0 && cy < R && cz < R) {
@@ -138,7 +189,7 @@ __global__ void __launch_bounds__(kBlock) k_brick_activity(Dev d, int nbx, int n
 
 // The pair sums of VelPos.compute:67-98 from the recorded list of slot s (n entries), then :100-157.
 template <int PREC, bool FAST>
-__device__ __forceinline__ void walk_list_and_integrate(const Dev &d, uint32_t s, uint32_t n, uint32_t mask, bool live,
+__device__ __forceinline__ Pos3 walk_list_and_integrate(const Dev &d, uint32_t s, uint32_t n, uint32_t mask, bool live,
                                                         float pix, float piy, float piz)
 {
     const float4 rvi = d.cur.rv[s];
@@ -199,7 +250,8 @@ __device__ __forceinline__ void walk_list_and_integrate(const Dev &d, uint32_t s
             a1 = b1;
         }
     }
-    if (live) integrate_store<PREC, FAST>(d, s, pix, piy, piz, vix, viy, viz, viw, rho_i, f);  // :100-157
+    if (live) return integrate_store<PREC, FAST>(d, s, pix, piy, piz, vix, viy, viz, viw, rho_i, f);  // :100-157
+    return Pos3{pix, piy, piz};
 }
 
 // VelPos.compute:46-158 for the targets of CALM bricks, one lane per slot: pair sums from the list recorded by the
@@ -256,7 +308,8 @@ __global__ void __launch_bounds__(kListBlock, SPH_LIST_MINWAVES) k_velpos_list(D
     if (live && (t.c0z + t.shz < d.zt_lo || t.c0z + t.shz > d.zt_hi)) atomicAdd(&d.counters[kCntHaloViolation], 1ull);
     enqueue_block(d, hand_over, s, s_queue, d.queue2, kCntQueue2);
     if (!live) n = 0;
-    walk_list_and_integrate<PREC, FAST>(d, s, n, t.mask, live, t.px, t.py, t.pz);
+    const Pos3 pn = walk_list_and_integrate<PREC, FAST>(d, s, n, t.mask, live, t.px, t.py, t.pz);
+    if (d.box_mode) box_update_wave(d, live, brick, pn.x - t.px, pn.y - t.py, pn.z - t.pz);   // (launch-uniform)
     stat_count(d, kStatListed, live);
     stat_add_u32(d, kStatListEntries, n);
 }
@@ -348,7 +401,7 @@ void launch_frame_report(const Dev &d, unsigned long long *report, bool lists_in
 void launch_list_prepare(const Dev &d, hipStream_t s)
 {
     const uint32_t nbx = nl_bricks_x(d.R), nby = nl_bricks_y(d.R), nbz = nl_bricks_z(d.R);
-    if (!d.nl_still) hipLaunchKernelGGL(k_chunk_box, dim3(cdiv(d.count, kBlock)), dim3(kBlock), 0, s, d);
+    if (!d.nl_still && !d.box_mode) hipLaunchKernelGGL(k_chunk_box, dim3(cdiv(d.count, kBlock)), dim3(kBlock), 0, s, d);
     // the brick layers along z with planes that hold targets (z-slab mode: this rank's planes)
     const int zl = d.zo_lo < 0 ? 0 : d.zo_lo, zh = d.zo_hi > (int)d.R ? (int)d.R : d.zo_hi;
     const uint32_t bl = (uint32_t)zl / kNlBZ, bh = zh > zl ? ((uint32_t)zh + kNlBZ - 1) / kNlBZ : bl;

@@ -189,9 +189,16 @@ __device__ __forceinline__ void velpos_target(const Dev &d, uint32_t s, bool liv
             }
         }
     }
+    Pos3 pn{pix, piy, piz};
     if (live) {
-        if (d.fast) integrate_store<-1, true>(d, s, pix, piy, piz, vix, viy, viz, viw, rho_i, f);   // tolerance mode (launch-uniform)
-        else integrate_store(d, s, pix, piy, piz, vix, viy, viz, viw, rho_i, f);
+        if (d.fast) pn = integrate_store<-1, true>(d, s, pix, piy, piz, vix, viy, viz, viw, rho_i, f);   // tolerance mode (launch-uniform)
+        else pn = integrate_store(d, s, pix, piy, piz, vix, viy, viz, viw, rho_i, f);
+    }
+    if (d.box_mode && d.nl_mode == kNlUse) {             // (launch-uniform) per-brick displacement ranges: the brick of the target's BIN
+        const Pos3 pb = load_binned(d, s);
+        const uint32_t key = bucket_key(d, pb.x, pb.y, pb.z);
+        const bool in_grid = live && key < d.num_cells;  // (limbo particles are nobody's candidates)
+        box_update_wave(d, in_grid, in_grid ? nl_brick_of_key(d, key) : 0u, pn.x - pix, pn.y - piy, pn.z - piz);
     }
 }
 

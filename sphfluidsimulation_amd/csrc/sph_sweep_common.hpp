@@ -346,6 +346,133 @@ __device__ __forceinline__ bool nl_blocked(const Dev &d)
     return launch_is_wild(d) || d.counters[kCntIrregular] != 0ull;
 }
 
+// min / max over the 16 lanes of a DPP row in four VALU steps (quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror, row_mirror:
+// every step pairs each lane with one that holds the other half), no LDS traffic
+template <bool MAX>
+__device__ __forceinline__ float row16_reduce(float v)
+{
+#define SPH_DPP_STEP(ctrl)                                                                                               \
+    {                                                                                                                    \
+        const float o = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), ctrl, 0xF, 0xF, false)); \
+        v = MAX ? fmaxf(v, o) : fminf(v, o);                                                                             \
+    }
+    SPH_DPP_STEP(0xB1) SPH_DPP_STEP(0x4E) SPH_DPP_STEP(0x141) SPH_DPP_STEP(0x140)
+#undef SPH_DPP_STEP
+    return v;
+}
+
+// ---- per-brick displacement ranges (Dev::box_mode; sph_kernels_list.hip) ----------------------------------------------------------
+// Fields of Dev read from the kernel-argument segment at the point of use (Dev is every kernel's first argument) behind an opaque
+// pointer: the compiler cannot keep them in registers across the caller's hot loop.  k_velpos_tile runs at its register limit,
+// and five more live scalars spilled a vector register there.
+typedef const __attribute__((address_space(4))) Dev *KernargDev;
+__device__ __forceinline__ KernargDev late_kernarg_dev()
+{
+    KernargDev p = (KernargDev)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    return p;
+}
+
+// A wave whose `on` lanes all belong to ONE brick (k_velpos_brick: the workgroup's) adds their displacements to the brick's range
+// of this sub-step: reduction in DPP steps within the rows of 16 lanes and two cross-row exchanges, six atomics from lane 0.
+__device__ __forceinline__ void box_update_uniform(const Dev &d, bool on, uint32_t brick, float dx, float dy, float dz)
+{
+    const float eps = d.prec ? d.h * 0x1p-14f : 0.0f;
+    float lo[3] = {on ? dx - eps : INFINITY, on ? dy - eps : INFINITY, on ? dz - eps : INFINITY};
+    float hi[3] = {on ? dx + eps : -INFINITY, on ? dy + eps : -INFINITY, on ? dz + eps : -INFINITY};
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        lo[a] = row16_reduce<false>(lo[a]);
+        hi[a] = row16_reduce<true>(hi[a]);
+        lo[a] = fminf(lo[a], __shfl_xor(lo[a], 16, kWave));
+        hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], 16, kWave));
+        lo[a] = fminf(lo[a], __shfl_xor(lo[a], 32, kWave));
+        hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], 32, kWave));
+    }
+    if ((threadIdx.x & (kWave - 1)) == 0 && lo[0] <= hi[0]) {                    // (somebody was on)
+        uint32_t *box = d.dbox + (size_t)d.box_par * 6u * d.n_bricks + brick;
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            atomicMin(box + (size_t)a * d.n_bricks, float_key(lo[a]));
+            atomicMax(box + (size_t)(3 + a) * d.n_bricks, float_key(hi[a]));
+        }
+    }
+}
+
+// Adds the displacements (dx, dy, dz) of the lanes that are `on` to the per-sub-step range of their bricks (Dev::dbox).  Every
+// lane of the wave must call it.  One round per distinct brick among the lanes -- one for the brick kernels, a few for the
+// kernels that walk slots; the range of a round is reduced across the wave and its first lane issues the six atomics.
+// eps: what the stored position may differ by from the one the displacement was taken from (precision 1: the fp16 record).
+__device__ __forceinline__ void box_update_wave(const Dev &d, bool on, uint32_t brick, float dx, float dy, float dz)
+{
+    const float eps = d.prec ? d.h * 0x1p-14f : 0.0f;
+    unsigned long long todo = __ballot(on);
+    const int lane = threadIdx.x & (kWave - 1);
+    while (todo) {                                                               // wave-uniform
+        const int leader = __ffsll((long long)todo) - 1;
+        const uint32_t b = __shfl(brick, leader, kWave);
+        const bool mine = on && brick == b;
+        float lo[3] = {mine ? dx - eps : INFINITY, mine ? dy - eps : INFINITY, mine ? dz - eps : INFINITY};
+        float hi[3] = {mine ? dx + eps : -INFINITY, mine ? dy + eps : -INFINITY, mine ? dz + eps : -INFINITY};
+        // (displacements are differences of clamped positions: finite)
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            lo[a] = row16_reduce<false>(lo[a]);
+            hi[a] = row16_reduce<true>(hi[a]);
+            lo[a] = fminf(lo[a], __shfl_xor(lo[a], 16, kWave));
+            hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], 16, kWave));
+            lo[a] = fminf(lo[a], __shfl_xor(lo[a], 32, kWave));
+            hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], 32, kWave));
+        }
+        if (lane == leader) {
+            uint32_t *box = d.dbox + (size_t)d.box_par * 6u * d.n_bricks + b;
+#pragma unroll
+            for (int a = 0; a < 3; a++) {
+                atomicMin(box + (size_t)a * d.n_bricks, float_key(lo[a]));
+                atomicMax(box + (size_t)(3 + a) * d.n_bricks, float_key(hi[a]));
+            }
+        }
+        todo &= ~__ballot(mine);
+    }
+}
+
+// k_velpos_tile's: the range of a wave in six DPP steps per value -- v_min_f32 / v_max_f32 with the DPP operand, written out
+// because the compiler emits v_mov_dpp + canonicalising v_max + v_min per step, and this code runs at the END of every wave's
+// life, where nothing hides it (what the kernel pays for its ranges, in any variant tried: ~4 % = 0.05 ms per launch, against
+// the 0.1 ms pass over all positions and the launch it replaces: profiles/r03b_experiments.txt).  Within the rows of 16
+// lanes (quad_perm x 2, row_half_mirror, row_mirror), then row_bcast:15 into rows 1 and 3 and row_bcast:31 into rows 2 and 3:
+// lane 63 holds the wave's range and writes its six keys to the wave's LDS slot; the workgroup combines the slots after its
+// barrier and STORES -- its brick's targets are its own, the kernels that integrate the few others (handed over, lists of
+// global slots) run later in the stream and add theirs with atomics.
+__device__ __forceinline__ void box_wave_range_to_lds(uint32_t *s_wave6, bool on, float dx, float dy, float dz, float eps)
+{
+    float lo[3] = {on ? dx - eps : INFINITY, on ? dy - eps : INFINITY, on ? dz - eps : INFINITY};
+    float hi[3] = {on ? dx + eps : -INFINITY, on ? dy + eps : -INFINITY, on ? dz + eps : -INFINITY};
+    // (s_nop 1: two wait states between a VALU write of a register and a DPP read of it)
+#define SPH_DPP6(op, v)                                                                           \
+    asm volatile("s_nop 1\n\t" op " %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t" \
+                 "s_nop 1\n\t" op " %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t" \
+                 "s_nop 1\n\t" op " %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"     \
+                 "s_nop 1\n\t" op " %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"          \
+                 "s_nop 1\n\t" op " %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"        \
+                 "s_nop 1\n\t" op " %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf"              \
+                 : "+v"(v))
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        SPH_DPP6("v_min_f32_dpp", lo[a]);
+        SPH_DPP6("v_max_f32_dpp", hi[a]);
+    }
+#undef SPH_DPP6
+    if ((threadIdx.x & (kWave - 1)) == kWave - 1) {
+        const bool any = lo[0] <= hi[0];                 // (nobody on: the empty range's keys, which lose every min / max)
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            s_wave6[a] = any ? float_key(lo[a]) : kBoxKeyEmptyLo;
+            s_wave6[3 + a] = any ? float_key(hi[a]) : kBoxKeyEmptyHi;
+        }
+    }
+}
+
 __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
 {
 #pragma unroll

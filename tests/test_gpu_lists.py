@@ -298,6 +298,42 @@ def test_scene_size_120_frames_default_context(oracle):
         sim.OnDestroy()
 
 
+def test_per_brick_and_per_chunk_displacement_ranges_agree(oracle):
+    """Which bricks may use their lists in a sub-step is decided from displacement ranges: per brick, accumulated where the
+    targets are integrated (the default), or per 64 slots from a pass over all positions (SPH_FLAG_CHUNK_BOXES; what z-slab
+    contexts use).  Either is only a sufficient condition -- the results are the oracle's bit for bit both ways -- and both
+    serve most target sub-steps of a flow that wakes some bricks."""
+    from sphfluidsimulation_amd.simulation import SphFluidSimulation
+    n, fill = 262144, 0.8
+    R = presets.scene_bucket_resolution(n)
+    pos0, vel0 = presets.dam_break(n, fill, seed=31, jitter=0.3)
+    rng = np.random.default_rng(7)
+    vel0[:, :3] = rng.standard_normal((n, 3)).astype(f32) * f32(0.3)
+    dt = presets.bench_dt_frame(R) * 0.25
+    frames = 3
+    outs = []
+    for chunk_boxes in (False, True):
+        sim = SphFluidSimulation(particleNumber=n, bucketResolution=R, damFillRate=fill, lists="always", chunk_boxes=chunk_boxes).Start(pos0, vel0)
+        try:
+            sim.reset_stats()
+            for _ in range(frames):
+                sim.Update(dt)
+            outs.append((sim.download(), sim.stats()))
+        finally:
+            sim.OnDestroy()
+    for a, b in zip(outs[0][0], outs[1][0]):
+        assert np.array_equal(_bits(a), _bits(b))
+    osim = oracle.OracleSimulation(oracle.derive(n, R, fill))
+    osim.upload(pos0, vel0)
+    for _ in range(frames):
+        osim.Update(dt)
+    for a, b in zip(outs[0][0], osim.download()):
+        assert np.array_equal(_bits(a), _bits(b))
+    fr = [o[1]["listed_target_substeps"] / (n * frames * 5) for o in outs]
+    assert 0.2 < fr[0] < 1.0 and 0.2 < fr[1] < 1.0, fr
+    assert outs[0][1]["scanned_brick_substeps"] > 0 and outs[1][1]["scanned_brick_substeps"] > 0
+
+
 @pytest.mark.parametrize("R", [47, 38])
 def test_tile_record_slots_agree(oracle, R):
     """k_velpos_tile takes a brick's tile set-up from the records the density pass wrote (whole brick, or -- where ~6
