@@ -489,6 +489,27 @@ __device__ __forceinline__ void stat_add_u32(const Dev &d, int stat, uint32_t v)
     if ((threadIdx.x & (kWave - 1)) == 0 && v)
         atomicAdd(&d.stripes[((size_t)stat * kStatStripes + (blockIdx.x % kStatStripes)) * kStatPad], (unsigned long long)v);
 }
+// the wave's sum of a u32 in six DPP steps (VALU only; lane 63 holds it), for kernels whose waves end on it: the exchanges of
+// stat_add_u32 go through the LDS pipe, ~12 dependent round trips at the end of a wave's life
+__device__ __forceinline__ uint32_t wave_sum_u32_dpp(uint32_t v)
+{
+    // row_shr:1,2,3 leave the sum of each group of 4 in its last lane; bank-masked row_shr:4 and :8 the sum of a row of 16 in
+    // lane 15; row_bcast:15 / :31 carry it across the rows (the wave reduction of the AMDGPU atomic optimiser)
+    asm volatile("s_nop 1\n\tv_add_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                 "s_nop 1\n\tv_add_u32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                 "s_nop 1\n\tv_add_u32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                 "s_nop 1\n\tv_add_u32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                 "s_nop 1\n\tv_add_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_add_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf"
+                 : "+v"(v));
+    return v;
+}
+__device__ __forceinline__ void stat_add_u32_dpp(const Dev &d, int stat, uint32_t v)
+{
+    v = wave_sum_u32_dpp(v);
+    if ((threadIdx.x & (kWave - 1)) == kWave - 1 && v)
+        atomicAdd(&d.stripes[((size_t)stat * kStatStripes + (blockIdx.x % kStatStripes)) * kStatPad], (unsigned long long)v);
+}
 // ... and for a per-lane flag: one ballot
 __device__ __forceinline__ void stat_count(const Dev &d, int stat, bool flag)
 {
