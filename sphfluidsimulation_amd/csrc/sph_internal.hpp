@@ -128,13 +128,17 @@ constexpr int kNlBX = 4, kNlBY = 4, kNlBZ = 4;   // brick shape of the VelPos ke
 //   [2c], [2c + 1]       tile cell c (z fastest): LDS offset | listed count << 16, first global slot   (one 8-byte load per thread)
 //   [kBrickRecRows + r]  first slot of owned row r;   [kBrickRecPref + r]  targets in the rows before r (r = 16: all of them)
 //   [kBrickRecStatus]    bit 0: the record is valid; bits 1..3: cells along x of its range (4 = the whole brick, 2 = a half);
-//                        bits 8..: listed particles of the tile
+//                        bits 8..17: listed particles of the tile; bits 18..: targets of the range (saturating)
 // kBrickRecSlots records per brick: [0] the whole brick, or its left half when the whole does not fit one tile; [1] the right half.
 //   [kBrickRecSrc + i]   global slot of the particle with tile index i (i < kBrickRecSrcCap)
+//   [kBrickRecTgt + 2t], [.. + 1]   the t-th target of the range (t < kBrickRecTgtCap): its slot; its own tile index (0xFFFF: it is
+//                        not one of the listed members of its cell) | owned row << 16 | cell along x within the range << 20
 constexpr int kBrickRecCells = (kNlBX + 2) * (kNlBY + 2) * (kNlBZ + 2);
 constexpr int kBrickRecRows = 2 * kBrickRecCells, kBrickRecPref = kBrickRecRows + kNlBY * kNlBZ,
               kBrickRecStatus = kBrickRecPref + kNlBY * kNlBZ + 1, kBrickRecSrc = 512, kBrickRecSrcCap = 1024,
-              kBrickRecWords = kBrickRecSrc + kBrickRecSrcCap, kBrickRecSlots = 2;
+              kBrickRecTgt = kBrickRecSrc + kBrickRecSrcCap, kBrickRecTgtCap = 256,
+              kBrickRecWords = kBrickRecTgt + 2 * kBrickRecTgtCap, kBrickRecSlots = 2;
+constexpr uint32_t kBrickRecTnMax = (1u << 14) - 1u;
 static_assert(kBrickRecStatus < kBrickRecSrc, "a brick record fits its stride");
 
 // order-preserving key of a float for integer atomic min / max (NaN sorts above +inf or below -inf: it reaches the decoder)
