@@ -116,7 +116,7 @@ def committed_csv(suffix, kernel_substr, tolerance=False):
             if not (kernel_substr + "<" in name or kernel_substr + "(" in name):  # (k_velpos_list, not k_velpos_list_changers)
                 continue
             m = re.search(re.escape(kernel_substr) + r"<([^>]*)>", name)
-            fast = bool(m) and m.group(1).split(",")[-1].strip() == "true"
+            fast = bool(m) and "true" in [x.strip() for x in m.group(1).split(",")]   # (the only bool among the template arguments)
             if fast == tolerance:
                 return row, os.path.relpath(f, ROOT) + " (16 777 216 particles)"
     return None, None

@@ -224,7 +224,7 @@ static void ensure_lists(SphContext *c)
                     dalloc(c, &d.active_list, bricks) == SPH_OK && dalloc(c, &d.queue2, n) == SPH_OK && dalloc(c, &d.brick_state, bricks + 4) == SPH_OK &&
                     dalloc(c, &d.cur.p4, n) == SPH_OK && dalloc(c, &d.nxt.p4, n) == SPH_OK &&
                     dalloc(c, &d.brick_rec, bricks * (size_t)(kBrickRecSlots * kBrickRecWords)) == SPH_OK &&
-                    dalloc(c, &d.dbox, 12 * bricks) == SPH_OK && dalloc(c, &d.cbox, 12 * bricks) == SPH_OK;
+                    dalloc(c, &d.boxrec, 2 * kBoxRecWords * bricks) == SPH_OK;
     if (!ok) {
         while (c->allocs.size() > before) {
             (void)hipFree(c->allocs.back());
@@ -240,8 +240,7 @@ static void ensure_lists(SphContext *c)
         d.queue2 = nullptr;
         d.brick_state = nullptr;
         d.brick_rec = nullptr;
-        d.dbox = nullptr;
-        d.cbox = nullptr;
+        d.boxrec = nullptr;
         d.cur.p4 = d.nxt.p4 = nullptr;
         c->nl_enabled = false;
         c->nl_unavailable = true;     // (sticky: a later sph_set_params must not try the multi-GB allocation again)

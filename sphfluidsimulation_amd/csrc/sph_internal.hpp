@@ -107,9 +107,10 @@ struct Dev {
     // k_brick_activity sums the ranges over the sub-steps of the frame (cbox) -- a superset of the range of the displacements
     // since the grid build, without a pass over all positions (k_chunk_box) per sub-step.
     uint32_t box_mode;     // 1: per-brick boxes; 0: k_chunk_box + chunk boxes (z-slab contexts: ghosts move without being integrated here)
-    uint32_t box_par;      // parity of the sub-step in flight within its frame: which half of dbox / cbox it writes
-    uint32_t *dbox;        // [2][6][bricks]: keys of min x,y,z / max x,y,z of the displacements of one sub-step
-    float *cbox;           // [2][6][bricks]: the ranges summed over the sub-steps so far
+    uint32_t box_par;      // parity of the sub-step in flight within its frame: which half of boxrec it writes
+    uint32_t *boxrec;      // [2][bricks][kBoxRecWords]: a 64-byte record per brick -- words 0..5 the keys of min x,y,z / max x,y,z of the
+                           //   displacements of ONE sub-step (what the kernels add to), words 6..11 the ranges summed over the sub-steps
+                           //   so far (floats, k_brick_activity's): a neighbour brick's twelve numbers in one cache line
     uint32_t tile_slots;   // which k_velpos_tile the launcher takes: 1 = whole-brick records, 2 = the records of halved bricks too
     uint32_t *brick_rec;   // [bricks][kBrickRecWords]: the set-up of every brick's LDS tile (cell table after the offset scan, owned
                            //   rows), written by the recording density pass and read back by k_velpos_tile in the S sub-steps of the
@@ -149,6 +150,7 @@ __device__ __forceinline__ uint32_t float_key(float f)
 }
 __device__ __forceinline__ float key_float(uint32_t k) { return __uint_as_float(k ^ ((k >> 31) ? 0x80000000u : 0xFFFFFFFFu)); }
 constexpr uint32_t kBoxKeyEmptyLo = 0xFFFFFFFFu, kBoxKeyEmptyHi = 0u;   // a range nobody has added to
+constexpr uint32_t kBoxRecWords = 16;
 
 __device__ __forceinline__ uint32_t *nl_entries(const Dev &d, uint32_t slot)   // entry e of the slot: [e * kWave]
 {

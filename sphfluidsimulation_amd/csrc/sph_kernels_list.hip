@@ -100,12 +100,15 @@ __global__ void __launch_bounds__(kBlock) k_brick_activity(Dev d, int nbx, int n
             const int nbz = (int)nl_bricks_z(d.R);
             if (bx >= 0 && by >= 0 && bz >= 0 && bx < nbx && by < nby && bz < nbz) {
                 const uint32_t n = (uint32_t)bx + (uint32_t)nbx * ((uint32_t)by + (uint32_t)nby * (uint32_t)bz);
-                const uint32_t *dk = d.dbox + (size_t)prev * 6u * nb + n;
-                const float *ck = d.cbox + (size_t)prev * 6u * nb + n;
+                const uint4 *rp = reinterpret_cast<const uint4 *>(d.boxrec + ((size_t)prev * nb + n) * kBoxRecWords);
+                const uint4 w0 = rp[0], w1 = rp[1], w2 = rp[2];      // keys lo xyz, hi x | hi yz, sums lo xy | sums lo z, hi xyz
+                const uint32_t keys[6] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y};
+                const float sums[6] = {__uint_as_float(w1.z), __uint_as_float(w1.w), __uint_as_float(w2.x), __uint_as_float(w2.y),
+                                       __uint_as_float(w2.z), __uint_as_float(w2.w)};
 #pragma unroll
                 for (int a = 0; a < 3; a++) {
-                    const uint32_t kl = dk[(size_t)a * nb], kh = dk[(size_t)(3 + a) * nb];
-                    float l = ck[(size_t)a * nb], h = ck[(size_t)(3 + a) * nb];
+                    const uint32_t kl = keys[a], kh = keys[3 + a];
+                    float l = sums[a], h = sums[3 + a];
                     mlo[a] = l; mhi[a] = h;
                     // (a brick nobody was integrated in holds no particle -- every particle is some kernel's target in every
                     // sub-step -- and stays out of the union)
@@ -117,13 +120,10 @@ __global__ void __launch_bounds__(kBlock) k_brick_activity(Dev d, int nbx, int n
             }
         }
         if (exists && lane == 13) {                    // the centre: this wave's own brick
-#pragma unroll
-            for (int a = 0; a < 3; a++) {
-                d.cbox[(size_t)par * 6u * nb + (size_t)a * nb + (uint32_t)b] = mlo[a];
-                d.cbox[(size_t)par * 6u * nb + (size_t)(3 + a) * nb + (uint32_t)b] = mhi[a];
-                d.dbox[(size_t)par * 6u * nb + (size_t)a * nb + (uint32_t)b] = kBoxKeyEmptyLo;
-                d.dbox[(size_t)par * 6u * nb + (size_t)(3 + a) * nb + (uint32_t)b] = kBoxKeyEmptyHi;
-            }
+            uint4 *wp = reinterpret_cast<uint4 *>(d.boxrec + ((size_t)par * nb + (uint32_t)b) * kBoxRecWords);
+            wp[0] = make_uint4(kBoxKeyEmptyLo, kBoxKeyEmptyLo, kBoxKeyEmptyLo, kBoxKeyEmptyHi);
+            wp[1] = make_uint4(kBoxKeyEmptyHi, kBoxKeyEmptyHi, __float_as_uint(mlo[0]), __float_as_uint(mlo[1]));
+            wp[2] = make_uint4(__float_as_uint(mlo[2]), __float_as_uint(mhi[0]), __float_as_uint(mhi[1]), __float_as_uint(mhi[2]));
         }
         if (d.nl_still) {
             // which bricks hold targets: from the rows of its bins, once per frame (later sub-steps keep the flag)

@@ -390,11 +390,11 @@ __device__ __forceinline__ void box_update_uniform(const Dev &d, bool on, uint32
         hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], 32, kWave));
     }
     if ((threadIdx.x & (kWave - 1)) == 0 && lo[0] <= hi[0]) {                    // (somebody was on)
-        uint32_t *box = d.dbox + (size_t)d.box_par * 6u * d.n_bricks + brick;
+        uint32_t *box = d.boxrec + ((size_t)d.box_par * d.n_bricks + brick) * kBoxRecWords;
 #pragma unroll
         for (int a = 0; a < 3; a++) {
-            atomicMin(box + (size_t)a * d.n_bricks, float_key(lo[a]));
-            atomicMax(box + (size_t)(3 + a) * d.n_bricks, float_key(hi[a]));
+            atomicMin(box + a, float_key(lo[a]));
+            atomicMax(box + 3 + a, float_key(hi[a]));
         }
     }
 }
@@ -425,11 +425,11 @@ __device__ __forceinline__ void box_update_wave(const Dev &d, bool on, uint32_t 
             hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], 32, kWave));
         }
         if (lane == leader) {
-            uint32_t *box = d.dbox + (size_t)d.box_par * 6u * d.n_bricks + b;
+            uint32_t *box = d.boxrec + ((size_t)d.box_par * d.n_bricks + b) * kBoxRecWords;
 #pragma unroll
             for (int a = 0; a < 3; a++) {
-                atomicMin(box + (size_t)a * d.n_bricks, float_key(lo[a]));
-                atomicMax(box + (size_t)(3 + a) * d.n_bricks, float_key(hi[a]));
+                atomicMin(box + a, float_key(lo[a]));
+                atomicMax(box + 3 + a, float_key(hi[a]));
             }
         }
         todo &= ~__ballot(mine);
