@@ -88,57 +88,6 @@ __global__ void __launch_bounds__(kBlock) k_brick_activity(Dev d, int nbx, int n
     float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
     bool own_nonempty = false;
     if (d.nl_still) lo[0] = lo[1] = lo[2] = hi[0] = hi[1] = hi[2] = 0.0f;   // first sub-step: every displacement is zero, no chunk boxes yet
-    if (d.box_mode) {
-        // Per-brick boxes (launch-uniform): lane l < 27 looks at neighbour brick l.  Its range so far = the sum of its per-sub-step
-        // ranges (cbox of the previous sub-step + the dbox the previous sub-step's kernels filled): the displacement of a particle
-        // since the grid build is the sum of its sub-step displacements, so it lies in the sum of the ranges.  The wave writes its
-        // OWN brick's new sum and resets its own dbox for the kernels of this sub-step (the other parity: nobody reads it now).
-        const uint32_t nb = d.n_bricks, par = d.box_par, prev = par ^ 1u;
-        float mlo[3] = {0.0f, 0.0f, 0.0f}, mhi[3] = {0.0f, 0.0f, 0.0f};    // (own brick, kept by lane 13)
-        if (!d.nl_still && lane < 27) {
-            const int bx = b % nbx + lane % 3 - 1, by = (b / nbx) % nby + (lane / 3) % 3 - 1, bz = b / (nbx * nby) + lane / 9 - 1;
-            const int nbz = (int)nl_bricks_z(d.R);
-            if (bx >= 0 && by >= 0 && bz >= 0 && bx < nbx && by < nby && bz < nbz) {
-                const uint32_t n = (uint32_t)bx + (uint32_t)nbx * ((uint32_t)by + (uint32_t)nby * (uint32_t)bz);
-                const uint4 *rp = reinterpret_cast<const uint4 *>(d.boxrec + ((size_t)prev * nb + n) * kBoxRecWords);
-                const uint4 w0 = rp[0], w1 = rp[1], w2 = rp[2];      // keys lo xyz, hi x | hi yz, sums lo xy | sums lo z, hi xyz
-                const uint32_t keys[6] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y};
-                const float sums[6] = {__uint_as_float(w1.z), __uint_as_float(w1.w), __uint_as_float(w2.x), __uint_as_float(w2.y),
-                                       __uint_as_float(w2.z), __uint_as_float(w2.w)};
-#pragma unroll
-                for (int a = 0; a < 3; a++) {
-                    const uint32_t kl = keys[a], kh = keys[3 + a];
-                    float l = sums[a], h = sums[3 + a];
-                    mlo[a] = l; mhi[a] = h;
-                    // (a brick nobody was integrated in holds no particle -- every particle is some kernel's target in every
-                    // sub-step -- and stays out of the union)
-                    if (kl != kBoxKeyEmptyLo || kh != kBoxKeyEmptyHi) {
-                        mlo[a] = lo[a] = l + key_float(kl);
-                        mhi[a] = hi[a] = h + key_float(kh);
-                    }
-                }
-            }
-        }
-        if (exists && lane == 13) {                    // the centre: this wave's own brick
-            uint4 *wp = reinterpret_cast<uint4 *>(d.boxrec + ((size_t)par * nb + (uint32_t)b) * kBoxRecWords);
-            wp[0] = make_uint4(kBoxKeyEmptyLo, kBoxKeyEmptyLo, kBoxKeyEmptyLo, kBoxKeyEmptyHi);
-            wp[1] = make_uint4(kBoxKeyEmptyHi, kBoxKeyEmptyHi, __float_as_uint(mlo[0]), __float_as_uint(mlo[1]));
-            wp[2] = make_uint4(__float_as_uint(mlo[2]), __float_as_uint(mhi[0]), __float_as_uint(mhi[1]), __float_as_uint(mhi[2]));
-        }
-        if (d.nl_still) {
-            // which bricks hold targets: from the rows of its bins, once per frame (later sub-steps keep the flag)
-            if (lane < kNlBY * kNlBZ) {
-                const int cy = y0 + lane % kNlBY, cz = z0 + lane / kNlBY;
-                if (cy < R && cz < R && x0 < R) {
-                    const int xb = x0 + kNlBX - 1 < R - 1 ? x0 + kNlBX - 1 : R - 1;
-                    const uint32_t rk = (uint32_t)cy * d.R + (uint32_t)cz * d.R * d.R;
-                    own_nonempty = d.cell_start[rk + (uint32_t)xb + 1u] > d.cell_start[rk + (uint32_t)x0];
-                }
-            }
-        } else {
-            own_nonempty = !(d.brick_state[b] & kBrickEmpty);
-        }
-    } else
     if (lane < kRY * kRZ) {
         const int cy = y0 - 1 + lane % kRY, cz = z0 - 1 + lane / kRY;
         if (cy >= 0 && cz >= 0 && cy < R && cz < R) {
@@ -165,6 +114,100 @@ __global__ void __launch_bounds__(kBlock) k_brick_activity(Dev d, int nbx, int n
             hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], o, kWave));
         }
     const bool nonempty = __any(own_nonempty);
+    uint32_t my_pos = 0xFFFFFFFFu;
+    if (lane == 0 && exists) {
+        float r2 = 0.0f, r[3];
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            r[a] = (hi[a] >= lo[a] ? hi[a] - lo[a] : 0.0f) * 1.00001f;   // empty neighbourhood: nothing moved
+            r2 += r[a] * r[a];
+        }
+        const float rho = sqrtf(r2) * 1.00001f;
+        const uint8_t st = d.brick_state[b] & kBrickUnlisted;
+        const bool active = blocked || st != 0 || !(rho <= d.skin_ok);   // NaN-safe
+        d.brick_state[b] = st | (active ? kBrickActive : 0) | (nonempty ? 0 : kBrickEmpty);   // (Empty: k_velpos_tile need not look)
+        if (active && nonempty && !blocked) atomicAdd(&d.counters[kCntActiveBricks], 1ull);
+        if (active) my_pos = atomicAdd(&s_act[0], 1u);
+    }
+    // the block's active bricks go to the work list of the scanning kernel with one atomic
+    __syncthreads();
+    if (threadIdx.x == 0 && s_act[0]) s_act[1] = (uint32_t)atomicAdd(&d.counters[kCntActiveCount], (unsigned long long)s_act[0]);
+    __syncthreads();
+    if (my_pos != 0xFFFFFFFFu) d.active_list[s_act[1] + my_pos] = (uint32_t)b;
+}
+
+// k_brick_activity with PER-BRICK displacement ranges (Dev::box_mode): HALF a wave per brick (8 bricks per block), lane l < 27
+// of the half looks at neighbour brick l.  A brick's range so far = the sum of its per-sub-step ranges (the sums up to the previous
+// sub-step + the range the previous sub-step's kernels filled): a particle's displacement since the grid build is the sum of its
+// sub-step displacements, so it lies in the sum of the ranges.  The half writes its OWN brick's new sums and resets its own
+// per-sub-step range for the kernels of this sub-step (the other parity of Dev::boxrec: nobody reads that now).
+// calm <=> every target of the brick has its list and the Euclidean norm of the ranges over the 27 bricks is <= skin_ok.
+__global__ void __launch_bounds__(kBlock) k_brick_activity_box(Dev d, int nbx, int nby, int first, int n_bricks)
+{
+    __shared__ uint32_t s_act[2];
+    constexpr int kHalf = 32, kPerBlock = kBlock / kHalf;
+    const int b_raw = first + blockIdx.x * kPerBlock + threadIdx.x / kHalf, lane = threadIdx.x & (kHalf - 1), R = (int)d.R;
+    const bool exists = b_raw < first + n_bricks;  // uniform per half; the launch covers the brick layers that hold targets
+    const int b = exists ? b_raw : first + n_bricks - 1;
+    const bool blocked = nl_blocked(d);            // then the scanning kernel takes every brick
+    if (threadIdx.x == 0) s_act[0] = 0;
+    __syncthreads();
+    const int bxi = b % nbx, byi = (b / nbx) % nby, bzi = b / (nbx * nby);
+    const uint32_t nb = d.n_bricks, par = d.box_par, prev = par ^ 1u;
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    float mlo[3] = {0.0f, 0.0f, 0.0f}, mhi[3] = {0.0f, 0.0f, 0.0f};        // (own brick, kept by lane 13)
+    bool own_nonempty = false;
+    if (d.nl_still) {
+        // first sub-step: every displacement is zero.  Which bricks hold targets: from the rows of its bins, once per frame
+        // (later sub-steps keep the flag)
+        lo[0] = lo[1] = lo[2] = hi[0] = hi[1] = hi[2] = 0.0f;
+        if (lane < kNlBY * kNlBZ) {
+            const int x0 = bxi * kNlBX, cy = byi * kNlBY + lane % kNlBY, cz = bzi * kNlBZ + lane / kNlBY;
+            if (cy < R && cz < R && x0 < R) {
+                const int xb = x0 + kNlBX - 1 < R - 1 ? x0 + kNlBX - 1 : R - 1;
+                const uint32_t rk = (uint32_t)cy * d.R + (uint32_t)cz * d.R * d.R;
+                own_nonempty = d.cell_start[rk + (uint32_t)xb + 1u] > d.cell_start[rk + (uint32_t)x0];
+            }
+        }
+    } else {
+        own_nonempty = !(d.brick_state[b] & kBrickEmpty);
+        if (lane < 27) {
+            const int bx = bxi + lane % 3 - 1, by = byi + (lane / 3) % 3 - 1, bz = bzi + lane / 9 - 1;
+            if (bx >= 0 && by >= 0 && bz >= 0 && bx < nbx && by < nby && bz < (int)nl_bricks_z(d.R)) {
+                const uint32_t n = (uint32_t)bx + (uint32_t)nbx * ((uint32_t)by + (uint32_t)nby * (uint32_t)bz);
+                const uint4 *rp = reinterpret_cast<const uint4 *>(d.boxrec + ((size_t)prev * nb + n) * kBoxRecWords);
+                const uint4 w0 = rp[0], w1 = rp[1], w2 = rp[2];      // keys lo xyz, hi x | hi yz, sums lo xy | sums lo z, hi xyz
+                const uint32_t keys[6] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y};
+                const float sums[6] = {__uint_as_float(w1.z), __uint_as_float(w1.w), __uint_as_float(w2.x), __uint_as_float(w2.y),
+                                       __uint_as_float(w2.z), __uint_as_float(w2.w)};
+#pragma unroll
+                for (int a = 0; a < 3; a++) {
+                    mlo[a] = sums[a]; mhi[a] = sums[3 + a];
+                    // (a brick nobody was integrated in holds no particle -- every particle is some kernel's target in every
+                    // sub-step -- and stays out of the union)
+                    if (keys[a] != kBoxKeyEmptyLo || keys[3 + a] != kBoxKeyEmptyHi) {
+                        mlo[a] = lo[a] = sums[a] + key_float(keys[a]);
+                        mhi[a] = hi[a] = sums[3 + a] + key_float(keys[3 + a]);
+                    }
+                }
+            }
+        }
+    }
+    if (exists && lane == 13) {                        // the centre: this half's own brick
+        uint4 *wp = reinterpret_cast<uint4 *>(d.boxrec + ((size_t)par * nb + (uint32_t)b) * kBoxRecWords);
+        wp[0] = make_uint4(kBoxKeyEmptyLo, kBoxKeyEmptyLo, kBoxKeyEmptyLo, kBoxKeyEmptyHi);
+        wp[1] = make_uint4(kBoxKeyEmptyHi, kBoxKeyEmptyHi, __float_as_uint(mlo[0]), __float_as_uint(mlo[1]));
+        wp[2] = make_uint4(__float_as_uint(mlo[2]), __float_as_uint(mhi[0]), __float_as_uint(mhi[1]), __float_as_uint(mhi[2]));
+    }
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+#pragma unroll
+        for (int o = kHalf / 2; o > 0; o >>= 1) {      // (xor with < 32 stays inside the half)
+            lo[a] = fminf(lo[a], __shfl_xor(lo[a], o, kWave));
+            hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], o, kWave));
+        }
+    const unsigned long long ne = __ballot(own_nonempty);
+    const bool nonempty = ((ne >> (threadIdx.x & kHalf)) & 0xFFFFFFFFull) != 0ull;   // (bit 5 of the lane index: which half)
     uint32_t my_pos = 0xFFFFFFFFu;
     if (lane == 0 && exists) {
         float r2 = 0.0f, r[3];
@@ -406,7 +449,10 @@ void launch_list_prepare(const Dev &d, hipStream_t s)
     const int zl = d.zo_lo < 0 ? 0 : d.zo_lo, zh = d.zo_hi > (int)d.R ? (int)d.R : d.zo_hi;
     const uint32_t bl = (uint32_t)zl / kNlBZ, bh = zh > zl ? ((uint32_t)zh + kNlBZ - 1) / kNlBZ : bl;
     const uint32_t count = nbx * nby * ((bh < nbz ? bh : nbz) - bl);
-    if (count)
+    if (count && d.box_mode)
+        hipLaunchKernelGGL(k_brick_activity_box, dim3(cdiv(count, kBlock / 32)), dim3(kBlock), 0, s, d, (int)nbx, (int)nby,
+                           (int)(nbx * nby * bl), (int)count);
+    else if (count)
         hipLaunchKernelGGL(k_brick_activity, dim3(cdiv(count, kBlock / kWave)), dim3(kBlock), 0, s, d, (int)nbx, (int)nby,
                            (int)(nbx * nby * bl), (int)count);
 }
