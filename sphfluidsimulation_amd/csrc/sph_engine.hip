@@ -1055,7 +1055,10 @@ int sph_set_params(SphContext *c, const SphParams *p)
     if (c->is_group) return group_set_params(c, p);
     // lists recorded by the density pass of the frame in flight (staged calls) were recorded FOR a format, a kernel set and a
     // skin: a change of any of them retires them (the rest of the frame scans; the next density pass records again)
-    constexpr uint32_t kListFlags = SPH_FLAG_GLOBAL_LISTS | SPH_FLAG_NO_TILING | SPH_FLAG_NO_LISTS;
+    // (the instantiation of k_velpos_tile goes with the decomposition the recording pass chose; the displacement ranges of the
+    // sub-steps so far are per brick or per chunk)
+    constexpr uint32_t kListFlags = SPH_FLAG_GLOBAL_LISTS | SPH_FLAG_NO_TILING | SPH_FLAG_NO_LISTS | SPH_FLAG_TILE_SLOTS_ONE |
+                                    SPH_FLAG_TILE_SLOTS_TWO | SPH_FLAG_CHUNK_BOXES;
     if (((p->flags ^ c->params.flags) & kListFlags) != 0u || p->list_skin != c->params.list_skin) c->nl_recorded = false;
     c->params = *p;
     c->profile = (p->flags & SPH_FLAG_PROFILE) != 0;
