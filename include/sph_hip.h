@@ -99,8 +99,8 @@ typedef struct SphParams {
                                       k_velpos_tile; same bits, slower */
 #define SPH_FLAG_TILE_SLOTS_ONE 512u  /* diagnostic: k_velpos_tile compiled for whole-brick records only (default: picked from the particles per cell) */
 #define SPH_FLAG_TILE_SLOTS_TWO 1024u /* diagnostic: k_velpos_tile compiled for the records of halved bricks too (config C4's regime) */
-#define SPH_FLAG_CHUNK_BOXES 2048u   /* diagnostic: displacement ranges per 64 slots from a pass over all positions per sub-step (k_chunk_box; what
-                                        z-slab contexts use) instead of per-brick ranges accumulated where targets are integrated */
+#define SPH_FLAG_CHUNK_BOXES 2048u   /* diagnostic: displacement ranges per 64 slots from a pass over all positions per sub-step (k_chunk_box,
+                                        rounds 1-2) instead of per-brick ranges accumulated where targets are integrated */
 #define SPH_FLAG_NO_GRAPHS 8u   /* diagnostic: sph_step issues its ~60 launches every frame instead of replaying a HIP graph */
 
 /* Values of the uniforms the reference pushes through ShaderIDs.cs:5-32. */

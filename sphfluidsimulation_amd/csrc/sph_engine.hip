@@ -73,7 +73,7 @@ void refresh_scalars(SphContext *c)
     d.prec = p.precision;
     d.fast = p.exact_order == 0u ? 1u : 0u;
     d.nl_tile = (p.flags & SPH_FLAG_GLOBAL_LISTS) ? 0u : 1u;
-    d.box_mode = c->slab || (p.flags & SPH_FLAG_CHUNK_BOXES) ? 0u : 1u;   // (ghosts move without being integrated by their slab: chunk boxes there)
+    d.box_mode = (p.flags & SPH_FLAG_CHUNK_BOXES) ? 0u : 1u;
     {
         // k_velpos_tile with one record slot or two (sph_brick_impl.inc): a brick is halved when the listed particles of its
         // halo-1 box (216 cells) exceed the 928-particle tile -- expected where the occupied cells hold more than ~4 particles
@@ -248,6 +248,7 @@ static void ensure_lists(SphContext *c)
         return;
     }
     c->nl_allocated = true;
+    launch_box_init(d, c->stream);
 }
 
 int do_bucket_generation(SphContext *c)

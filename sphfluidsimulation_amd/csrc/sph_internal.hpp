@@ -106,7 +106,7 @@ struct Dev {
     // displacement of THIS sub-step to the range of its bin's brick (dbox, atomic min / max on order-preserving keys);
     // k_brick_activity sums the ranges over the sub-steps of the frame (cbox) -- a superset of the range of the displacements
     // since the grid build, without a pass over all positions (k_chunk_box) per sub-step.
-    uint32_t box_mode;     // 1: per-brick boxes; 0: k_chunk_box + chunk boxes (z-slab contexts: ghosts move without being integrated here)
+    uint32_t box_mode;     // 1: per-brick boxes; 0: k_chunk_box + chunk boxes (SPH_FLAG_CHUNK_BOXES)
     uint32_t box_par;      // parity of the sub-step in flight within its frame: which half of boxrec it writes
     uint32_t *boxrec;      // [2][bricks][kBoxRecWords]: a 64-byte record per brick -- words 0..5 the keys of min x,y,z / max x,y,z of the
                            //   displacements of ONE sub-step (what the kernels add to), words 6..11 the ranges summed over the sub-steps
@@ -356,6 +356,7 @@ void launch_grid_build(const Dev &d, hipStream_t s);  // keys, histogram, scan, 
 void launch_density(const Dev &d, hipStream_t s);     // sph_kernels_brick.hip (tiled) + queue
 // cur -> nxt; the optional events bracket k_velpos_list (recorded only in a sub-step that uses neighbour lists)
 void launch_velpos(const Dev &d, hipStream_t s, hipEvent_t list_begin = nullptr, hipEvent_t list_end = nullptr);
+void launch_box_init(const Dev &d, hipStream_t s);      // sph_kernels_list.hip: per-brick displacement ranges, once after allocation
 void launch_list_prepare(const Dev &d, hipStream_t s);  // sph_kernels_list.hip: which bricks may use their lists
 void launch_frame_report(const Dev &d, unsigned long long *report, bool lists_in_use, hipStream_t s);   // sph_kernels_list.hip
 void launch_velpos_tile_lists(const Dev &d, hipStream_t s, hipEvent_t list_begin = nullptr, hipEvent_t list_end = nullptr);  // sph_kernels_brick_density.hip

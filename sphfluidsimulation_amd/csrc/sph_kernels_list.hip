@@ -142,7 +142,10 @@ __global__ void __launch_bounds__(kBlock) k_brick_activity(Dev d, int nbx, int n
 // sub-step displacements, so it lies in the sum of the ranges.  The half writes its OWN brick's new sums and resets its own
 // per-sub-step range for the kernels of this sub-step (the other parity of Dev::boxrec: nobody reads that now).
 // calm <=> every target of the brick has its list and the Euclidean norm of the ranges over the 27 bricks is <= skin_ok.
-__global__ void __launch_bounds__(kBlock) k_brick_activity_box(Dev d, int nbx, int nby, int first, int n_bricks)
+// z-slab contexts: the launch also covers the brick layers made of ghost planes only (t_first, t_count: the bricks with target
+// planes) -- their ranges are summed and reset like the others (the ghost refresh adds the ghosts' displacements,
+// k_slab_unpack_update), they have no state and never go to the work list.
+__global__ void __launch_bounds__(kBlock) k_brick_activity_box(Dev d, int nbx, int nby, int first, int n_bricks, int t_first, int t_count)
 {
     __shared__ uint32_t s_act[2];
     constexpr int kHalf = 32, kPerBlock = kBlock / kHalf;
@@ -209,7 +212,7 @@ __global__ void __launch_bounds__(kBlock) k_brick_activity_box(Dev d, int nbx, i
     const unsigned long long ne = __ballot(own_nonempty);
     const bool nonempty = ((ne >> (threadIdx.x & kHalf)) & 0xFFFFFFFFull) != 0ull;   // (bit 5 of the lane index: which half)
     uint32_t my_pos = 0xFFFFFFFFu;
-    if (lane == 0 && exists) {
+    if (lane == 0 && exists && b >= t_first && b < t_first + t_count) {
         float r2 = 0.0f, r[3];
 #pragma unroll
         for (int a = 0; a < 3; a++) {
@@ -228,6 +231,22 @@ __global__ void __launch_bounds__(kBlock) k_brick_activity_box(Dev d, int nbx, i
     if (threadIdx.x == 0 && s_act[0]) s_act[1] = (uint32_t)atomicAdd(&d.counters[kCntActiveCount], (unsigned long long)s_act[0]);
     __syncthreads();
     if (my_pos != 0xFFFFFFFFu) d.active_list[s_act[1] + my_pos] = (uint32_t)b;
+}
+
+// every brick's record (both parities) to "nobody was integrated here, nothing has moved": once, when the buffers are allocated
+// (k_brick_activity_box keeps the bricks it covers; the ones beyond a slab's ghost layers are only ever read)
+__global__ void __launch_bounds__(kBlock) k_box_init(Dev d)
+{
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= 2u * d.n_bricks) return;
+    uint4 *wp = reinterpret_cast<uint4 *>(d.boxrec + (size_t)i * kBoxRecWords);
+    wp[0] = make_uint4(kBoxKeyEmptyLo, kBoxKeyEmptyLo, kBoxKeyEmptyLo, kBoxKeyEmptyHi);
+    wp[1] = make_uint4(kBoxKeyEmptyHi, kBoxKeyEmptyHi, 0u, 0u);
+    wp[2] = make_uint4(0u, 0u, 0u, 0u);
+}
+void launch_box_init(const Dev &d, hipStream_t s)
+{
+    if (d.boxrec && d.n_bricks) hipLaunchKernelGGL(k_box_init, dim3((2u * d.n_bricks + kBlock - 1) / kBlock), dim3(kBlock), 0, s, d);
 }
 
 // The pair sums of VelPos.compute:67-98 from the recorded list of slot s (n entries), then :100-157.
@@ -449,10 +468,15 @@ void launch_list_prepare(const Dev &d, hipStream_t s)
     const int zl = d.zo_lo < 0 ? 0 : d.zo_lo, zh = d.zo_hi > (int)d.R ? (int)d.R : d.zo_hi;
     const uint32_t bl = (uint32_t)zl / kNlBZ, bh = zh > zl ? ((uint32_t)zh + kNlBZ - 1) / kNlBZ : bl;
     const uint32_t count = nbx * nby * ((bh < nbz ? bh : nbz) - bl);
-    if (count && d.box_mode)
-        hipLaunchKernelGGL(k_brick_activity_box, dim3(cdiv(count, kBlock / 32)), dim3(kBlock), 0, s, d, (int)nbx, (int)nby,
-                           (int)(nbx * nby * bl), (int)count);
-    else if (count)
+    if (count && d.box_mode) {
+        // z-slab contexts: + the layers that hold ghost planes (halo_w = zo_lo - zt_lo + 1 planes per face that has a neighbour)
+        const int gl = d.zt_lo == INT_MIN ? zl : (zl - (d.zo_lo - d.zt_lo + 1) > 0 ? zl - (d.zo_lo - d.zt_lo + 1) : 0);
+        const int gh = d.zt_hi == INT_MAX ? zh : (zh + (d.zt_hi - d.zo_hi + 2) < (int)d.R ? zh + (d.zt_hi - d.zo_hi + 2) : (int)d.R);
+        const uint32_t cl = (uint32_t)gl / kNlBZ, ch0 = ((uint32_t)gh + kNlBZ - 1) / kNlBZ, ch = ch0 < nbz ? ch0 : nbz;
+        const uint32_t cover = nbx * nby * (ch - cl);
+        hipLaunchKernelGGL(k_brick_activity_box, dim3(cdiv(cover, kBlock / 32)), dim3(kBlock), 0, s, d, (int)nbx, (int)nby,
+                           (int)(nbx * nby * cl), (int)cover, (int)(nbx * nby * bl), (int)count);
+    } else if (count)
         hipLaunchKernelGGL(k_brick_activity, dim3(cdiv(count, kBlock / kWave)), dim3(kBlock), 0, s, d, (int)nbx, (int)nby,
                            (int)(nbx * nby * bl), (int)count);
 }

@@ -219,9 +219,11 @@ __global__ void __launch_bounds__(kBlock) k_slab_unpack_update(Dev d, uint32_t s
                                                                const float *__restrict__ in)
 {
     const uint32_t k = blockIdx.x * kBlock + threadIdx.x;
-    if (k >= n) return;
-    const uint32_t s = d.slot_of_src[src0 + k];
-    if (what == 0) {
+    const bool have = k < n;
+    const uint32_t s = have ? d.slot_of_src[src0 + k] : 0u;
+    if (!have) {
+        // (no ghost for this lane; it still takes part in the wave's range reduction below)
+    } else if (what == 0) {
         d.cur.rv[s].x = in[k];
         if (is_wild_density(d, in[k])) d.counters[kCntWildP] = 1ull;    // (as the density pass does for local particles)
     } else {
@@ -233,6 +235,21 @@ __global__ void __launch_bounds__(kBlock) k_slab_unpack_update(Dev d, uint32_t s
         }
         d.cur.rv[s] = make_float4(r[3], r[4], r[5], r[6]);
         if (is_wild(r[4]) || is_wild(r[5]) || is_wild(r[6])) d.counters[kCntWildV0 + d.wild_v_cur] = 1ull;
+    }
+    if (what != 0 && d.box_mode && d.nl_mode == kNlUse) {   // (launch-uniform)
+        // per-brick displacement ranges (sph_kernels_list.hip): a ghost is nobody's target here -- its displacement of this
+        // sub-step (d.cur = what the sub-step writes, d.nxt = what it read) goes to the range of its bin's brick with its refresh
+        bool on = false;
+        uint32_t brick = 0;
+        float dx = 0.0f, dy = 0.0f, dz = 0.0f;
+        if (have) {
+            const Pos3 pb = load_binned(d, s), pn = load_pos(d, d.cur, s), po = load_pos(d, d.nxt, s);
+            const uint32_t key = bucket_key(d, pb.x, pb.y, pb.z);
+            on = key < d.num_cells;
+            brick = on ? nl_brick_of_key(d, key) : 0u;
+            dx = pn.x - po.x; dy = pn.y - po.y; dz = pn.z - po.z;
+        }
+        box_update_wave(d, on, brick, dx, dy, dz);
     }
 }
 
