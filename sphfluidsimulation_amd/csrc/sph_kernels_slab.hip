@@ -238,7 +238,9 @@ __global__ void __launch_bounds__(kBlock) k_slab_unpack_update(Dev d, uint32_t s
     }
     if (what != 0 && d.box_mode && d.nl_mode == kNlUse) {   // (launch-uniform)
         // per-brick displacement ranges (sph_kernels_list.hip): a ghost is nobody's target here -- its displacement of this
-        // sub-step (d.cur = what the sub-step writes, d.nxt = what it read) goes to the range of its bin's brick with its refresh
+        // sub-step (d.cur = what the sub-step writes, d.nxt = what it read) goes to the range of its bin's brick with its refresh.
+        // (Rounds per brick within the wave, 22 us per call at 8 slabs of 16.7 M; one set of atomics per ghost: 68 us -- the
+        // ghosts of a brick meet on six addresses.  The owner's own per-brick ranges, sent along, would be cheaper still.)
         bool on = false;
         uint32_t brick = 0;
         float dx = 0.0f, dy = 0.0f, dz = 0.0f;
