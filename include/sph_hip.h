@@ -101,6 +101,7 @@ typedef struct SphParams {
 #define SPH_FLAG_TILE_SLOTS_TWO 1024u /* diagnostic: k_velpos_tile compiled for the records of halved bricks too (config C4's regime) */
 #define SPH_FLAG_CHUNK_BOXES 2048u   /* diagnostic: displacement ranges per 64 slots from a pass over all positions per sub-step (k_chunk_box,
                                         rounds 1-2) instead of per-brick ranges accumulated where targets are integrated */
+#define SPH_FLAG_NO_SIDE_STREAM 4096u /* diagnostic: the scanning kernel of a sub-step in stream order instead of beside the list kernels */
 #define SPH_FLAG_NO_GRAPHS 8u   /* diagnostic: sph_step issues its ~60 launches every frame instead of replaying a HIP graph */
 
 /* Values of the uniforms the reference pushes through ShaderIDs.cs:5-32. */

@@ -27,6 +27,7 @@ SPH_FLAG_GLOBAL_LISTS = 256
 SPH_FLAG_TILE_SLOTS_ONE = 512
 SPH_FLAG_TILE_SLOTS_TWO = 1024
 SPH_FLAG_CHUNK_BOXES = 2048
+SPH_FLAG_NO_SIDE_STREAM = 4096
 SPH_COMM_ID_BYTES = 128
 SPH_SLAB_UPDATE_RHO = 0
 SPH_SLAB_UPDATE_POSVEL = 1

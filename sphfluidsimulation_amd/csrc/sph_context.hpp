@@ -106,6 +106,8 @@ struct SphContext {
     uint32_t capacity = 0;            // particles the device arrays can hold
     int z_lo = 0, z_hi = 0, halo_w = 2, has_left = 0, has_right = 0;
     SlabRank *rank = nullptr;         // exchange buffers, counts, snapshot (allocated by sph_slab_configure)
+    hipStream_t side_stream = nullptr;   // plain contexts: the scanning kernel of a list-using sub-step runs here, beside the list kernels
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipStream_t comm_stream = nullptr;   // the halo refresh of a two-pass sub-step travels here while `stream` computes
     SlabGroup *group = nullptr;       // the group that steps this slab (owned by the group context, or by this context when it
                                       // is the only local member: one process per GPU)

@@ -307,10 +307,10 @@ static void velpos_issue(SphContext *c, uint32_t pass_mode)
         pe.kind = 3;
         pe.a = get_event(c);
         pe.b = get_event(c);
-        launch_velpos(d, c->stream, pe.a, pe.b);
+        launch_velpos(d, c->stream, pe.a, pe.b, c->side_stream, c->ev_fork, c->ev_join);
         c->pending.push_back(pe);
     } else {
-        launch_velpos(d, c->stream);
+        launch_velpos(d, c->stream, nullptr, nullptr, c->side_stream, c->ev_fork, c->ev_join);
     }
 }
 
@@ -452,6 +452,15 @@ static int create_common(const SphParams *params, uint32_t capacity, bool slab, 
         fail(c, SPH_E_HIP, "hipSetDevice(%d) failed", c->device);
         return bail(SPH_E_HIP);
     }
+    // (plain contexts: a side stream for the scanning kernel of a list-using sub-step, sph_brick_impl.inc launch_velpos; without it
+    // -- SPH_FLAG_NO_SIDE_STREAM, z-slab contexts -- everything is issued in stream order)
+    if (!slab && !(params->flags & SPH_FLAG_NO_SIDE_STREAM) &&
+        (hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking) != hipSuccess ||
+         hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
+         hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess)) {
+        (void)hipGetLastError();
+        c->side_stream = nullptr;
+    }
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
         fail(c, SPH_E_HIP, "hipStreamCreate failed");
         return bail(SPH_E_HIP);
@@ -566,6 +575,9 @@ int sph_destroy(SphContext *c)
     if (c->ext_sem) (void)hipDestroyExternalSemaphore(c->ext_sem);
     if (c->owns_group && c->group) slab_group_destroy(c->group);
     slab_rank_destroy(c);
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    if (c->side_stream) (void)hipStreamDestroy(c->side_stream);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return SPH_OK;

@@ -355,7 +355,10 @@ void launch_clear(const Dev &d, uint32_t counter_mask, uint32_t stat_mask, hipSt
 void launch_grid_build(const Dev &d, hipStream_t s);  // keys, histogram, scan, scatter, id-sort, reorder: cur -> nxt
 void launch_density(const Dev &d, hipStream_t s);     // sph_kernels_brick.hip (tiled) + queue
 // cur -> nxt; the optional events bracket k_velpos_list (recorded only in a sub-step that uses neighbour lists)
-void launch_velpos(const Dev &d, hipStream_t s, hipEvent_t list_begin = nullptr, hipEvent_t list_end = nullptr);
+// side / ev_fork / ev_join (optional): the scanning kernel over the few bricks that are not calm runs on `side`, beside the list
+// kernels on `s` (forked after k_brick_activity, joined before the queue kernel)
+void launch_velpos(const Dev &d, hipStream_t s, hipEvent_t list_begin = nullptr, hipEvent_t list_end = nullptr,
+                   hipStream_t side = nullptr, hipEvent_t ev_fork = nullptr, hipEvent_t ev_join = nullptr);
 void launch_box_init(const Dev &d, hipStream_t s);      // sph_kernels_list.hip: per-brick displacement ranges, once after allocation
 void launch_list_prepare(const Dev &d, hipStream_t s);  // sph_kernels_list.hip: which bricks may use their lists
 void launch_frame_report(const Dev &d, unsigned long long *report, bool lists_in_use, hipStream_t s);   // sph_kernels_list.hip

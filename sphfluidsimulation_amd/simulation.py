@@ -30,7 +30,7 @@ class SphFluidSimulation:
                  dampingCoefficient: float = 10.0, device_id: int = 0, profile: bool = False,
                  tiling: bool = True, lists: bool = True, graphs: bool = True, particleRadius: float = 0.01, lowSpeed: float = 0.0,
                  highSpeed: float = 0.5, substeps: int = 5, device_ids=None, halo_planes: int = 0, list_skin: float = 0.0,
-                 peer_copies: bool = False, precision: int = 0, overlap: bool = True, exact_order: bool = True, tile_lists: bool = True, tile_slots: int = 0, chunk_boxes: bool = False):
+                 peer_copies: bool = False, precision: int = 0, overlap: bool = True, exact_order: bool = True, tile_lists: bool = True, tile_slots: int = 0, chunk_boxes: bool = False, side_stream: bool = True):
         # inspector fields and defaults, SphFluidSimulation.cs:35-45
         self.preset = preset
         self.particleNumber = particleNumber
@@ -56,6 +56,7 @@ class SphFluidSimulation:
         self.halo_planes = halo_planes  # ghost planes per slab face to start with (0 = 2)
         self.list_skin = list_skin      # neighbour-list skin / h (0 = 0.04)
         self.precision = precision      # 1: positions stored as fp16 offsets from the cell centre (config C4)
+        self.side_stream = side_stream  # False: the scanning kernel in stream order (SPH_FLAG_NO_SIDE_STREAM, diagnostic)
         self.chunk_boxes = chunk_boxes  # True: displacement ranges from k_chunk_box (SPH_FLAG_CHUNK_BOXES, diagnostic)
         self.tile_slots = tile_slots    # 1 / 2: force the k_velpos_tile instantiation (SPH_FLAG_TILE_SLOTS_*, diagnostic); 0: the engine picks
         self.tile_lists = tile_lists    # False: lists of global slots gathered through L1 by k_velpos_list (SPH_FLAG_GLOBAL_LISTS, diagnostic)
@@ -91,7 +92,7 @@ class SphFluidSimulation:
                    (N.SPH_FLAG_LISTS_ALWAYS if self.lists == "always" else 0) | (N.SPH_FLAG_PEER_COPIES if self.peer_copies else 0) | (0 if self.overlap else N.SPH_FLAG_NO_OVERLAP) |
                    (0 if self.tile_lists else N.SPH_FLAG_GLOBAL_LISTS) |
                    {0: 0, 1: N.SPH_FLAG_TILE_SLOTS_ONE, 2: N.SPH_FLAG_TILE_SLOTS_TWO}[int(self.tile_slots)] |
-                   (N.SPH_FLAG_CHUNK_BOXES if self.chunk_boxes else 0))
+                   (N.SPH_FLAG_CHUNK_BOXES if self.chunk_boxes else 0) | (0 if self.side_stream else N.SPH_FLAG_NO_SIDE_STREAM))
         return p
 
     def _check(self, rc):
