@@ -46,6 +46,7 @@ struct SphContext {
         uint32_t substeps = 0;
         bool recorded_lists = false;  // the captured density pass recorded neighbour lists
         bool lists_on = false;        // neighbour lists were enabled and allocated at capture time
+        bool fork_scan = false;       // the scanning kernel was captured on the side stream
     } graph[2];
     bool graphs_enabled = false;
     float *dt_dev = nullptr;          // delta_time / dt_divisor of the frame being replayed (device scalar)
@@ -108,6 +109,8 @@ struct SphContext {
     SlabRank *rank = nullptr;         // exchange buffers, counts, snapshot (allocated by sph_slab_configure)
     hipStream_t side_stream = nullptr;   // plain contexts: the scanning kernel of a list-using sub-step runs here, beside the list kernels
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    bool fork_scan = false;              // ... while the last reported frame had many bricks that were not calm (update_scan_policy)
+    unsigned long long scan_seen[2] = {0, 0};
     hipStream_t comm_stream = nullptr;   // the halo refresh of a two-pass sub-step travels here while `stream` computes
     SlabGroup *group = nullptr;       // the group that steps this slab (owned by the group context, or by this context when it
                                       // is the only local member: one process per GPU)

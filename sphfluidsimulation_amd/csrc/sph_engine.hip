@@ -307,10 +307,10 @@ static void velpos_issue(SphContext *c, uint32_t pass_mode)
         pe.kind = 3;
         pe.a = get_event(c);
         pe.b = get_event(c);
-        launch_velpos(d, c->stream, pe.a, pe.b, c->side_stream, c->ev_fork, c->ev_join);
+        launch_velpos(d, c->stream, pe.a, pe.b, c->fork_scan ? c->side_stream : nullptr, c->ev_fork, c->ev_join);
         c->pending.push_back(pe);
     } else {
-        launch_velpos(d, c->stream, nullptr, nullptr, c->side_stream, c->ev_fork, c->ev_join);
+        launch_velpos(d, c->stream, nullptr, nullptr, c->fork_scan ? c->side_stream : nullptr, c->ev_fork, c->ev_join);
     }
 }
 
@@ -493,9 +493,9 @@ static int create_common(const SphParams *params, uint32_t capacity, bool slab, 
     c->graphs_enabled = !slab && !c->profile && !(params->flags & SPH_FLAG_NO_GRAPHS);
     {
         void *h = nullptr, *dv = nullptr;
-        if (hipHostMalloc(&h, 4 * sizeof(unsigned long long), hipHostMallocMapped) == hipSuccess &&
+        if (hipHostMalloc(&h, 8 * sizeof(unsigned long long), hipHostMallocMapped) == hipSuccess &&
             hipHostGetDevicePointer(&dv, h, 0) == hipSuccess) {
-            memset(h, 0, 4 * sizeof(unsigned long long));
+            memset(h, 0, 8 * sizeof(unsigned long long));
             c->report_host = (volatile unsigned long long *)h;
             c->report_dev = (unsigned long long *)dv;
         } else {
@@ -900,6 +900,23 @@ static int issue_frame(SphContext *c, float dt)
 
 static bool frame_reports(const SphContext *c) { return c->report_dev && c->nl_enabled && !c->slab; }
 
+// Where the scanning kernel of a list-using sub-step runs (launch_velpos): beside the list kernels on the side stream while the
+// last reported frame had many bricks that were not calm (late in a dam break: thousands per sub-step, 2.3 ms of a 42 ms frame
+// that overlap with the list kernels -> 40.4 ms), in stream order while it had a handful (the calm frames of the bench: no gain,
+// and a kernel profile in which the two kernels' durations mean what they say).
+static void update_scan_policy(SphContext *c)
+{
+    if (!c->report_host || !c->side_stream) return;
+    const unsigned long long frames = c->report_host[0], bricks = c->report_host[4];
+    if (frames == c->scan_seen[0]) return;
+    if (frames > c->scan_seen[0] && bricks >= c->scan_seen[1]) {
+        const double per_substep = (double)(bricks - c->scan_seen[1]) / ((double)(frames - c->scan_seen[0]) * (double)c->params.substeps);
+        c->fork_scan = per_substep > 1000.0;
+    }
+    c->scan_seen[0] = frames;
+    c->scan_seen[1] = bricks;
+}
+
 // Decides, before a frame is issued, whether it records neighbour lists (see SphContext::pol_*).
 static void update_list_policy(SphContext *c)
 {
@@ -973,6 +990,7 @@ int sph_step(SphContext *c, float delta_time)
     HIP_TRY(c, hipSetDevice(c->device));
     const float dt = delta_time / c->params.dt_divisor;                 // :102 Time.deltaTime / 25
     update_list_policy(c);
+    update_scan_policy(c);
     if (c->pol_on) ensure_lists(c);   // (never inside a stream capture)
     grow_list_rows(c);
     if (frame_reports(c)) c->pol_issued++;
@@ -1000,7 +1018,8 @@ int sph_step(SphContext *c, float delta_time)
     start.nl_still = 0;
     start.box_par = 0;
     const bool lists_on = c->nl_enabled && c->nl_allocated && c->pol_on;
-    if (!g.exec || g.substeps != c->params.substeps || g.lists_on != lists_on || memcmp(&g.start, &start, sizeof(Dev)) != 0) {
+    if (!g.exec || g.substeps != c->params.substeps || g.lists_on != lists_on || g.fork_scan != c->fork_scan ||
+        memcmp(&g.start, &start, sizeof(Dev)) != 0) {
         if (g.exec) (void)hipGraphExecDestroy(g.exec);
         g.exec = nullptr;
         hipGraph_t graph = nullptr;
@@ -1035,6 +1054,7 @@ int sph_step(SphContext *c, float delta_time)
         memcpy(&g.start, &start, sizeof(Dev));
         g.substeps = c->params.substeps;
         g.lists_on = lists_on;
+        g.fork_scan = c->fork_scan;
     }
     HIP_TRY(c, hipGraphLaunch(g.exec, c->stream));
     c->graph_replays++;

@@ -447,6 +447,11 @@ __global__ void __launch_bounds__(kStatStripes) k_frame_report(Dev d, unsigned l
         report[1] = total;
         report[2] += lists_in_use ? 1ull : 0ull;
         if (lists_in_use) report[3] = d.counters[kCntListTooLong];   // targets whose list did not fit nl_cap this frame
+        {   // [4]: brick sub-steps the scanning kernel took, cumulative whatever sph_reset_stats does to the counter ([5]: its last value)
+            const unsigned long long cur = d.counters[kCntActiveBricks], last = report[5];
+            report[4] += cur >= last ? cur - last : cur;
+            report[5] = cur;
+        }
         __threadfence_system();
         report[0] += 1ull;                         // last: the host takes [1], [2] only as fresh as [0]
         __threadfence_system();
