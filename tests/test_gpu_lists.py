@@ -428,7 +428,10 @@ def test_random_configurations_all_paths(oracle, seed):
     vel0[:, :3] = rng.standard_normal((n, 3)).astype(f32) * f32(speed)
     dt = float(rng.uniform(0.05, 1.0)) / (R - 1 if R > 1 else 1) * 0.7666667
     frames = int(rng.integers(3, 9))
-    sim = SphFluidSimulation(particleNumber=n, bucketResolution=R, damFillRate=fill, lists=lists, **scal).Start(pos0, vel0)
+    # (round 3: which k_velpos_tile instantiation walks the lists, where the displacement ranges come from, where the scanning
+    # kernel runs -- none of it may change a bit)
+    route = dict(tile_slots=int(rng.choice([0, 1, 2])), chunk_boxes=bool(rng.integers(0, 2)), side_stream=bool(rng.integers(0, 2)))
+    sim = SphFluidSimulation(particleNumber=n, bucketResolution=R, damFillRate=fill, lists=lists, **route, **scal).Start(pos0, vel0)
     osim = oracle.OracleSimulation(oracle.derive(n, R, fill, viscosity=scal["viscosity"], rest_density=scal["restDensity"],
                                                  gas_constant=scal["gasConstant"], stiffness=scal["stiffnessCoefficient"],
                                                  damping=scal["dampingCoefficient"]))
@@ -439,6 +442,6 @@ def test_random_configurations_all_paths(oracle, seed):
             osim.Update(dt)
         for a, b, name in zip(sim.download(), osim.download(), ("pos", "vel", "rho")):
             same = (_bits(a) == _bits(b)) | (np.isnan(a) & np.isnan(b))
-            assert same.all(), f"{name}: n={n} R={R} fill={fill} speed={speed} lists={lists} frames={frames}"
+            assert same.all(), f"{name}: n={n} R={R} fill={fill} speed={speed} lists={lists} frames={frames} route={route}"
     finally:
         sim.OnDestroy()
