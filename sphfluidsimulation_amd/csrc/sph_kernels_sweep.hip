@@ -157,7 +157,7 @@ __device__ __forceinline__ void velpos_target(const Dev &d, uint32_t s, bool liv
                         // branch-free append: always store at n, keep it only if the slot is a survivor (superset of |r| < h,
                         // VelPos.compute:37,43); n <= kListCap - 32 on entry to a cell leaves room
                         list[(((n >> 1) * kBlock + tid) << 1) + (n & 1u)] = (uint16_t)((ci << 5) | k);
-                        n += (k < cr.cnt && j != s && r2 < d.h2_up) ? 1u : 0u;
+                        n += (uint32_t)(k < cr.cnt) & (uint32_t)(j != s) & (uint32_t)(r2 < d.h2_up);   // (no short circuit: no branch)
                     }
                 }
                 if (__any(n > (uint32_t)(kListCap - kMaxPerVoxel))) {            // next cell may not fit
