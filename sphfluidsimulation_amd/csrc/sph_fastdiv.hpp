@@ -8,9 +8,9 @@
 //     a == 0 or b == 0 | exp(a)-exp(b) >= 96 | b denormal | 1/b denormal | a/b denormal | exp(a) <= 23.
 // Outside those cases the sequence is plain arithmetic on the operands themselves, and VelPos.compute divides SEVEN
 // numerators by two denominators per pair (3 x |r|, 4 x rho_j or 2 rho_j: :37, :93, :94): the refined reciprocal `r`
-// (v_rcp + two fma) is computed once per denominator, the six remaining instructions per numerator are the compiler's
-// own, operation for operation, so the quotient is bit-identical to `/`.  v_div_fixup stays: it gives a zero numerator
-// its signed zero exactly as in the full expansion.
+// (v_rcp + two fma) is computed once per denominator; the remaining instructions per numerator are the compiler's own
+// (SPH_DIV_ONE_STEP 0) or one correction step fewer (1, checked exhaustively: below), so the quotient is bit-identical to
+// `/`.  v_div_fixup stays where signed zeros matter: it gives a zero numerator its signed zero exactly as in the full expansion.
 //
 // Window in which the callers may use it (everything else takes `/`; the test is ONE min-tree over the numerators'
 // bit patterns per pair, see pair_unsafe_bits):
@@ -40,28 +40,56 @@ __device__ __forceinline__ Recip recip_refined(float b)
 // reciprocal of 2b from the one of b: every step of the refinement scales exactly by 1/2
 __device__ __forceinline__ Recip recip_twice(const Recip &d) { return Recip{2.0f * d.b, 0.5f * d.r}; }
 
-__device__ __forceinline__ float div_shared(float a, const Recip &d)
+// SPH_DIV_ONE_STEP 1: ONE correction step per numerator, q1 = fma(fma(-b, q0, a), r, q0) with q0 = a r (3 instructions instead of the
+// compiler's 5).  Markstein's theorem gives the correctly rounded quotient from one step when r = RN(1 / b); on gfx950 v_rcp_f32 plus
+// the one Newton step of recip_refined IS RN(1 / b) for every significand, and q1 == a / b for ALL 2^23 x 2^23 significand pairs:
+// scripts/ubench/div_exhaustive.hip (7.0e13 pairs on the device, 47 s, 0 mismatches; profiles/r03b_div_exhaustive.txt).  Inside the
+// window below nothing is scaled and every step commutes with powers of two, so the significands decide; the exponents are covered
+// by sph_selftest_arithmetic's random operands.  0: the compiler's two steps, operation for operation.
+#ifndef SPH_DIV_ONE_STEP
+#define SPH_DIV_ONE_STEP 1
+#endif
+__device__ __forceinline__ float div_shared_nofix(float a, const Recip &d)
 {
     const float q0 = a * d.r;
     const float e0 = __builtin_fmaf(-d.b, q0, a);
     const float q1 = __builtin_fmaf(e0, d.r, q0);
+#if SPH_DIV_ONE_STEP
+    return q1;
+#else
     const float e1 = __builtin_fmaf(-d.b, q1, a);
-    const float q2 = __builtin_fmaf(e1, d.r, q1);          // v_div_fmas with VCC = 0
-    return __builtin_amdgcn_div_fixupf(q2, d.b, a);
+    return __builtin_fmaf(e1, d.r, q1);                    // v_div_fmas with VCC = 0
+#endif
 }
 
-// sqrtf(x) for x == 0 or x >= 2^-96 finite: v_sqrt (1 ulp) + the compiler's own one-ulp correction, without its
-// 2^32 pre-scaling of tiny arguments and without the zero / inf pass-through (zero passes through the correction
-// unharmed).  For 0 < x < 2^-96 the result is some value in [0, 2^-47]: the callers only compare it with 1e-6 and
-// subtract it from h >= 2^-8, which every such value leaves unchanged.
+// ... with v_div_fixup: the sign of a zero quotient (and inf / NaN operands) exactly as in the compiler's expansion
+__device__ __forceinline__ float div_shared(float a, const Recip &d) { return __builtin_amdgcn_div_fixupf(div_shared_nofix(a, d), d.b, a); }
+
+// sqrtf(x) for x == 0 or x >= 2^-96 finite, without the compiler's 2^32 pre-scaling of tiny arguments and without its zero / inf
+// pass-through.  For 0 < x < 2^-96 the result is some value in [0, 2^-47]: the callers only compare it with 1e-6 and subtract it
+// from h >= 2^-8, which every such value leaves unchanged.
+//   SPH_SQRT_RESIDUAL 1: s = v_sqrt(x) (1 ulp), one residual step s + (x - s^2) * (0.5 * v_rsq(x)) with the residual exact in an fma
+//     (Markstein's final step; 2 transcendental + 4 plain instructions).  0.5 / sqrt(x) is capped at 2^47, its value at x = 2^-96:
+//     for x = 0 the step then adds 0 * 2^47 instead of 0 * inf.  Equal to sqrtf on EVERY float of [2^-96, 2^101):
+//     scripts/ubench/sqrt_exhaustive.hip (197 x 2^23 arguments on the device, 0 mismatches).
+//   SPH_SQRT_RESIDUAL 0: v_sqrt + the compiler's own one-ulp correction (2 integer adds, 2 fma, 2 compares, 2 selects: the six
+//     that are not fma cost 4.3 cycles per wave each on gfx950 against 2.9).
+#ifndef SPH_SQRT_RESIDUAL
+#define SPH_SQRT_RESIDUAL 0
+#endif
 __device__ __forceinline__ float sqrt_unscaled(float x)
 {
     float s = __builtin_amdgcn_sqrtf(x);
+#if SPH_SQRT_RESIDUAL
+    const float hr = __builtin_fminf(0.5f * __builtin_amdgcn_rsqf(x), 0x1p47f);
+    return __builtin_fmaf(__builtin_fmaf(-s, s, x), hr, s);
+#else
     const float sd = __uint_as_float(__float_as_uint(s) - 1u), su = __uint_as_float(__float_as_uint(s) + 1u);
     const float rd = __builtin_fmaf(-sd, s, x), ru = __builtin_fmaf(-su, s, x);
     s = (0.0f >= rd) ? sd : s;
     s = (0.0f < ru) ? su : s;
     return s;
+#endif
 }
 
 // Bit pattern of |a| shifted so that unsigned order == magnitude order and zero sorts LAST: (bits << 1) - 1.

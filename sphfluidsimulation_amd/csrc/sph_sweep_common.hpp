@@ -154,16 +154,8 @@ __device__ __forceinline__ void pair_finish(const PairPre &q, Force &f)
 //     cp * 0 = +-0 (cp finite: ok), which leaves a sum that is never -0 unchanged, as adding +0 does; a quotient by
 //     |r| <= 1e-6 (inf, NaN) only ever reaches a select that drops it;
 //   * the guard of grad_W_vis (:43) folded into the select of its sum the same way (q_xyz finite: |dv| < 2e15, rho_j > 1e-6);
-//   * no v_div_fixup: inside the window of sph_fastdiv.hpp it only restores the sign of a zero quotient, and a zero
+//   * no v_div_fixup (div_shared_nofix, sph_fastdiv.hpp): inside the window of sph_fastdiv.hpp it only restores the sign of a zero quotient, and a zero
 //     quotient of either sign contributes +-0.
-__device__ __forceinline__ float div_shared_nofix(float a, const Recip &d)
-{
-    const float q0 = a * d.r;
-    const float e0 = __builtin_fmaf(-d.b, q0, a);
-    const float q1 = __builtin_fmaf(e0, d.r, q0);
-    const float e1 = __builtin_fmaf(-d.b, q1, a);
-    return __builtin_fmaf(e1, d.r, q1);
-}
 // rr_r: the refined reciprocal of rho_j, recip_refined(q.rho_j).r -- a caller that holds it (k_velpos_tile stages it with the
 // candidate) passes it in, everybody else computes it here.
 __device__ __forceinline__ void pair_finish_folded(const Dev &d, const PairPre &q, Force &f, float rr_r)
@@ -182,6 +174,26 @@ __device__ __forceinline__ void pair_finish_folded(const Dev &d, const PairPre &
     f.vx += sel_v ? ux : 0.0f;
     f.vy += sel_v ? uy : 0.0f;
     f.vz += sel_v ? uz : 0.0f;
+}
+// The same with the guards on OPERANDS (k_velpos_tile): |r| replaced by 1 where the pressure guard fails, the staged reciprocal of
+// rho_j being 0 where rho_j <= epsilon (tile_put), every quotient is finite, and a sum needs one select on its scalar factor
+// (cp, grad_W_vis) instead of three on its terms -- a failing pair adds cp_sel * gp = +-0.  Three selects per pair instead of six
+// (a select costs 4.3 cycles per wave on gfx950, a multiply-add 2.9).
+__device__ __forceinline__ void pair_finish_masked(const Dev &d, const PairPre &q, Force &f, float rr_r)
+{
+    const float abs_r_s = q.in_p ? q.abs_r : 1.0f;
+    const Recip ra = recip_refined(abs_r_s), rr{q.rho_j, rr_r}, r2 = recip_twice(rr);
+    const float gpx = div_shared_nofix(q.ngx, ra), gpy = div_shared_nofix(q.ngy, ra), gpz = div_shared_nofix(q.ngz, ra);
+    const float cp = div_shared_nofix(q.ncp, r2);
+    const float qx = div_shared_nofix(q.nvx, rr), qy = div_shared_nofix(q.nvy, rr), qz = div_shared_nofix(q.nvz, rr);
+    const float gv = d.c_over_h6 * (d.h - q.abs_r);                              // :43 without its guard
+    const float cps = (q.ok && q.in_p) ? cp : 0.0f, gvs = (q.ok && (q.abs_r < d.h)) ? gv : 0.0f;
+    f.px += cps * gpx;
+    f.py += cps * gpy;
+    f.pz += cps * gpz;
+    f.vx += qx * gvs;
+    f.vy += qy * gvs;
+    f.vz += qz * gvs;
 }
 __device__ __forceinline__ void pair_finish_folded(const Dev &d, const PairPre &q, Force &f)
 {
