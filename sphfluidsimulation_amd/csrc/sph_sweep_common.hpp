@@ -78,7 +78,9 @@ struct PairPre {
     bool sc_small;         // sc < 2^-27: a nonzero sc * r component may lie below the numerator window (pair_window_by_operands)
 };
 
-template <bool FAST>
+// RHO_GUARD false: `ok` is `take` alone -- for pair_finish_masked with a staged reciprocal that is 0 where rho_j <= epsilon (every
+// quotient by rho_j is then an exact 0 and the pair adds +-0, like the select on the guard).
+template <bool FAST, bool RHO_GUARD = true>
 __device__ __forceinline__ PairPre pair_pre(const Dev &d, float rx, float ry, float rz, float rho_j, float vjx, float vjy,
                                             float vjz, float vix, float viy, float viz, float p_i, bool take)
 {
@@ -86,7 +88,7 @@ __device__ __forceinline__ PairPre pair_pre(const Dev &d, float rx, float ry, fl
     const float h = d.h;
     PairPre q;
     const float p_j = d.gas_const * (rho_j - d.rest_density);                    // :87
-    q.ok = take && (rho_j > epsilon);                                            // :91
+    q.ok = RHO_GUARD ? take && (rho_j > epsilon) : take;                         // :91
     const float r2 = (rx * rx + ry * ry) + rz * rz;
     q.abs_r = FAST ? sqrt_unscaled(r2) : sqrtf(r2);                              // :35, :42
     const float diff_r = h - q.abs_r;                                            // :36
