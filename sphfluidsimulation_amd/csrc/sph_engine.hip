@@ -219,7 +219,7 @@ static void ensure_lists(SphContext *c)
     const bool binned = d.prec ? dalloc(c, &d.p1h, n) == SPH_OK
                                : dalloc(c, &d.p1x, n) == SPH_OK && dalloc(c, &d.p1y, n) == SPH_OK && dalloc(c, &d.p1z, n) == SPH_OK;
     const bool ok = binned &&
-                    dalloc(c, &d.nl_ent, (size_t)d.nl_cap * ((n + 63) & ~(size_t)63)) == SPH_OK && dalloc(c, &d.nl_cnt, n) == SPH_OK &&
+                    dalloc(c, &d.nl_ent, (size_t)d.nl_cap * ((n + 63) & ~(size_t)63) + kNlRowsPad * kWave) == SPH_OK && dalloc(c, &d.nl_cnt, n) == SPH_OK &&
                     dalloc(c, &d.chunk_box, 6 * ((n + kChunkSlots - 1) / kChunkSlots)) == SPH_OK &&
                     dalloc(c, &d.active_list, bricks) == SPH_OK && dalloc(c, &d.queue2, n) == SPH_OK && dalloc(c, &d.brick_state, bricks + 4) == SPH_OK &&
                     dalloc(c, &d.cur.p4, n) == SPH_OK && dalloc(c, &d.nxt.p4, n) == SPH_OK &&
@@ -369,7 +369,7 @@ static void grow_list_rows(SphContext *c)
     const size_t n = c->capacity;
     uint32_t *rows = nullptr;
     (void)hipStreamSynchronize(c->stream);
-    if (hipMalloc((void **)&rows, (size_t)cap * ((n + 63) & ~(size_t)63) * sizeof(uint32_t)) != hipSuccess) {
+    if (hipMalloc((void **)&rows, ((size_t)cap * ((n + 63) & ~(size_t)63) + kNlRowsPad * kWave) * sizeof(uint32_t)) != hipSuccess) {
         (void)hipGetLastError();
         c->nl_cap_want = 256u;        // (no memory for longer rows: stop asking)
         return;

@@ -152,6 +152,9 @@ __device__ __forceinline__ float key_float(uint32_t k) { return __uint_as_float(
 constexpr uint32_t kBoxKeyEmptyLo = 0xFFFFFFFFu, kBoxKeyEmptyHi = 0u;   // a range nobody has added to
 constexpr uint32_t kBoxRecWords = 16;
 
+// k_velpos_tile asks for entry rows up to kNlRowsPad rows ahead without looking at a list's length: rows past its end are rows of the
+// next 64 slots, or of the padding behind the last ones (Dev::nl_ent is allocated with kNlRowsPad more rows; never used: the walk ends first).
+constexpr uint32_t kNlRowsPad = 4;
 __device__ __forceinline__ uint32_t *nl_entries(const Dev &d, uint32_t slot)   // entry e of the slot: [e * kWave]
 {
     return d.nl_ent + ((size_t)(slot / kWave) * d.nl_cap) * kWave + (slot % kWave);

@@ -19,6 +19,9 @@ namespace sph {
 // Which format the brick kernel records: Dev::nl_tile (tile indices unless SPH_FLAG_GLOBAL_LISTS) -- see DESIGN.md 4.
 constexpr uint32_t kNlTileFormat = 0x8000u, kNlCountMask = 0x7FFFu;
 constexpr uint32_t kNlTileIdxBits = 11;          // tiles hold <= 2048 listed particles
+// An odd list's last row is completed with kNlTilePad: stencil cell 31, which no target's stencil mask has (27 cells), tile index 0
+// (a staged particle: its fields are read and dropped) -- the walk takes both halves of every row without asking for the length.
+constexpr uint32_t kNlTilePad = 31u << kNlTileIdxBits;
 
 __device__ __forceinline__ uint16_t *nl_tile_entry(uint32_t *row0, uint32_t e)   // row0 = nl_entries(d, slot)
 {
