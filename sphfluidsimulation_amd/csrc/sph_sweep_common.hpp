@@ -184,12 +184,14 @@ __device__ __forceinline__ void pair_finish_folded(const Dev &d, const PairPre &
 __device__ __forceinline__ void pair_finish_masked(const Dev &d, const PairPre &q, Force &f, float rr_r)
 {
     const float abs_r_s = q.in_p ? q.abs_r : 1.0f;
-    const Recip ra = recip_refined(abs_r_s), rr{q.rho_j, rr_r}, r2 = recip_twice(rr);
+    const Recip ra = recip_refined(abs_r_s), rr{q.rho_j, rr_r};
     const float gpx = div_shared_nofix(q.ngx, ra), gpy = div_shared_nofix(q.ngy, ra), gpz = div_shared_nofix(q.ngz, ra);
-    const float cp = div_shared_nofix(q.ncp, r2);
+    // :93 divides by 2 rho_j: half the quotient by rho_j (both scalings by two are exact: rho_j < 2^30, the quotient >= 2^-120)
+    const float cp = 0.5f * div_shared_nofix(q.ncp, rr);
     const float qx = div_shared_nofix(q.nvx, rr), qy = div_shared_nofix(q.nvy, rr), qz = div_shared_nofix(q.nvz, rr);
-    const float gv = d.c_over_h6 * (d.h - q.abs_r);                              // :43 without its guard
-    const float cps = (q.ok && q.in_p) ? cp : 0.0f, gvs = (q.ok && (q.abs_r < d.h)) ? gv : 0.0f;
+    // :43, c (h - |r|) where |r| < h and 0 elsewhere, is max(c (h - |r|), 0): h - |r| is exact in sign (positive iff |r| < h) and c > 0
+    const float gv = __builtin_fmaxf(d.c_over_h6 * (d.h - q.abs_r), 0.0f);
+    const float cps = (q.ok && q.in_p) ? cp : 0.0f, gvs = q.ok ? gv : 0.0f;
     f.px += cps * gpx;
     f.py += cps * gpy;
     f.pz += cps * gpz;
