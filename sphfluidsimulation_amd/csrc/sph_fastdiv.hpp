@@ -72,15 +72,25 @@ __device__ __forceinline__ float div_shared(float a, const Recip &d) { return __
 //     (Markstein's final step; 2 transcendental + 4 plain instructions).  0.5 / sqrt(x) is capped at 2^47, its value at x = 2^-96:
 //     for x = 0 the step then adds 0 * 2^47 instead of 0 * inf.  Equal to sqrtf on EVERY float of [2^-96, 2^101):
 //     scripts/ubench/sqrt_exhaustive.hip (197 x 2^23 arguments on the device, 0 mismatches).
-//   SPH_SQRT_RESIDUAL 0: v_sqrt + the compiler's own one-ulp correction (2 integer adds, 2 fma, 2 compares, 2 selects: the six
-//     that are not fma cost 4.3 cycles per wave each on gfx950 against 2.9).
+//   SPH_SQRT_RESIDUAL 0: v_sqrt + the compiler's own one-ulp correction (2 integer adds, 2 fma, 2 compares, 2 selects).
+//   SPH_SQRT_RESIDUAL 2: from v_rsq alone, sqrt and half its reciprocal refined together (1 transcendental + 8 plain; exhaustively equal too).
+//   k_velpos_tile with 0 / 1 / 2: 1.125 / 1.118 / 1.130 ms -- the walk pays per instruction, nearly whatever the instruction.
 #ifndef SPH_SQRT_RESIDUAL
-#define SPH_SQRT_RESIDUAL 0
+#define SPH_SQRT_RESIDUAL 1
 #endif
 __device__ __forceinline__ float sqrt_unscaled(float x)
 {
     float s = __builtin_amdgcn_sqrtf(x);
-#if SPH_SQRT_RESIDUAL
+#if SPH_SQRT_RESIDUAL == 2
+    // from v_rsq alone (1 transcendental + 8 plain): g ~ sqrt(x) and h ~ 1 / (2 sqrt(x)) refined together once, then the residual step
+    const float y = __builtin_fminf(__builtin_amdgcn_rsqf(x), 0x1p48f);
+    float g = x * y, h = 0.5f * y;
+    const float r = __builtin_fmaf(-h, g, 0.5f);
+    g = __builtin_fmaf(g, r, g);
+    h = __builtin_fmaf(h, r, h);
+    (void)s;
+    return __builtin_fmaf(__builtin_fmaf(-g, g, x), h, g);
+#elif SPH_SQRT_RESIDUAL
     const float hr = __builtin_fminf(0.5f * __builtin_amdgcn_rsqf(x), 0x1p47f);
     return __builtin_fmaf(__builtin_fmaf(-s, s, x), hr, s);
 #else
