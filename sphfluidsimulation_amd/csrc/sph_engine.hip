@@ -911,7 +911,10 @@ static void update_scan_policy(SphContext *c)
     if (frames == c->scan_seen[0]) return;
     if (frames > c->scan_seen[0] && bricks >= c->scan_seen[1]) {
         const double per_substep = (double)(bricks - c->scan_seen[1]) / ((double)(frames - c->scan_seen[0]) * (double)c->params.substeps);
-        c->fork_scan = per_substep > 1000.0;
+#ifndef SPH_SCAN_FORK_MIN
+#define SPH_SCAN_FORK_MIN 1000.0   /* bricks per sub-step that are not calm, above which the scanning kernel gets the side stream */
+#endif
+        c->fork_scan = per_substep > SPH_SCAN_FORK_MIN;
     }
     c->scan_seen[0] = frames;
     c->scan_seen[1] = bricks;
