@@ -79,11 +79,10 @@ __device__ __forceinline__ uint32_t shifted_mask(const ListTarget &t)
 {
     const uint32_t ax = t.shx > 0 ? 6u : (t.shx < 0 ? 3u : 7u), ay = t.shy > 0 ? 6u : (t.shy < 0 ? 3u : 7u),
                    az = t.shz > 0 ? 6u : (t.shz < 0 ? 3u : 7u);
-    uint32_t mask = 0;
-#pragma unroll
-    for (int code = 0; code < 27; code++)
-        if (((ax >> (code / 9)) & (ay >> ((code / 3) % 3)) & (az >> (code % 3))) & 1u) mask |= 1u << code;
-    return mask;
+    // bit (9 i + 3 j + k) = bit i of ax & bit j of ay & bit k of az: a product of the three 3-bit sets spread to their strides
+    // (no carries: the partial products do not overlap) -- a dozen instructions where the loop over the 27 cells took ~160
+    const uint32_t sy = (ay & 1u) | ((ay & 2u) << 2) | ((ay & 4u) << 4), sx = (ax & 1u) | ((ax & 2u) << 8) | ((ax & 4u) << 16);
+    return az * sy * sx;
 }
 
 }  // namespace sph
